@@ -1,0 +1,136 @@
+/* sfmx.h — C ABI of the MI355X-native SfM hot path (libsfmx.so, gfx950).
+ *
+ * The reference (RoozbehSanaei/Structure-from-Motion-3D-Reconstruction, cpp/) has no plugin / FFI
+ * layer: its hot functions are file-static in cpp/src/templering_sfm.cpp ("T:" below).  Each entry
+ * point here replaces one of those function seams and is what a maintainer would
+ * bind from the reference's own code (see INTEGRATION.md for the call-site patch).
+ *
+ * Conventions
+ *  - plain C, no exceptions across the boundary; every call returns an sfmx_status (0 = ok).
+ *  - caller owns host buffers; the library owns device memory inside the context.
+ *  - one HIP stream per context; a context is thread-compatible, not thread-safe (one per thread).
+ *  - all floating point is IEEE binary64, evaluated WITHOUT fused multiply-add in the reference's
+ *    operation order, so results are bit-identical to the x86-64 reference build.
+ *  - arrays of 2-D points are [n][2] doubles (x,y), row-major 3x3 matrices are 9 doubles.
+ */
+#ifndef SFMX_H
+#define SFMX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sfmx_status {
+  SFMX_OK = 0,
+  SFMX_ERR_INVALID = 1,   /* bad argument (null pointer, size <= 0, level out of range, ...)      */
+  SFMX_ERR_HIP = 2,       /* a HIP runtime call failed; see sfmx_last_error()                      */
+  SFMX_ERR_NO_DEVICE = 3, /* no gfx950 device / extension unusable: callers must fail, not fall back */
+  SFMX_ERR_SINGULAR = 4,  /* sfmx_solve_dense: pivot < 1e-15 — where dense.hpp:67 throws           */
+  SFMX_ERR_UNSUPPORTED = 5
+} sfmx_status;
+
+typedef struct sfmx_ctx sfmx_ctx;
+typedef struct sfmx_pyramid sfmx_pyramid;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int sfmx_ctx_create(int device_id, sfmx_ctx** out);
+void sfmx_ctx_destroy(sfmx_ctx* ctx);
+const char* sfmx_last_error(const sfmx_ctx* ctx);
+int sfmx_sync(sfmx_ctx* ctx);
+/* raw hipStream_t of the context (for event timing by the caller) */
+void* sfmx_stream(sfmx_ctx* ctx);
+/* microseconds of GPU time of the most recent hot kernel launched by the last API call, measured
+ * with HIP events on the context stream (0 when timing is disabled, see sfmx_set_timing). */
+int sfmx_set_timing(sfmx_ctx* ctx, int enabled);
+double sfmx_last_kernel_us(const sfmx_ctx* ctx);
+
+/* ---- image pyramid: replaces sfm::GrayImage + build_pyr/downsample2 (T:200-232) ------------ */
+/* level 0 is the image itself; level l is (w>>l) x (h>>l), 2x2 box with integer /4 truncation and
+ * +1 neighbours clamped to the edge.  All levels live in one HBM allocation. */
+int sfmx_pyramid_create(sfmx_ctx* ctx, int w, int h, int levels, sfmx_pyramid** out);
+void sfmx_pyramid_destroy(sfmx_ctx* ctx, sfmx_pyramid* pyr);
+/* host pixels -> HBM, then build levels 1.. on the device */
+int sfmx_pyramid_upload(sfmx_ctx* ctx, sfmx_pyramid* pyr, const uint8_t* host_pixels);
+/* pixels already resident in HBM (device pointer): device copy + build */
+int sfmx_pyramid_set_device(sfmx_ctx* ctx, sfmx_pyramid* pyr, const void* device_pixels);
+int sfmx_pyramid_download_level(sfmx_ctx* ctx, const sfmx_pyramid* pyr, int level, uint8_t* host_out);
+int sfmx_pyramid_level_size(const sfmx_pyramid* pyr, int level, int* w, int* h);
+
+/* ---- Shi-Tomasi score map: replaces the per-pixel loop of shi_tomasi (T:242-272) ----------- */
+/* score_out [h][w] doubles (0 outside the r=2 interior band); max_out = max over the map (T:274).
+ * Thresholding, std::sort and the greedy min-distance pick (T:275-301) stay on the host because
+ * their result depends on libstdc++'s sort permutation. */
+int sfmx_shi_tomasi_score(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double* score_out, double* max_out);
+/* candidates only: pixels with score >= max*quality in row-major order (T:280-285), as
+ * (x | y<<16) in cand_xy and the score in cand_score.  *n_out is the total number of candidates;
+ * at most cap are written. */
+int sfmx_shi_tomasi_candidates(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double quality, int cap,
+                               uint32_t* cand_xy, double* cand_score, int* n_out, double* max_out);
+
+/* ---- KLT: replaces KLTTracker::track_one fwd+bwd and the FB test (T:356-362, 402-460) ------- */
+typedef struct sfmx_klt_cfg {
+  int levels;       /* LKConfig::pyr_levels (T:312) */
+  int win_radius;   /* LKConfig::win_radius (T:313); supported 1..7 */
+  int iters;        /* LKConfig::iters (T:314) */
+  double fb_thresh; /* LKConfig::fb_thresh (T:315) */
+} sfmx_klt_cfg;
+/* For every point: fwd = track_one(A,B,p), back = track_one(B,A,fwd), keep = !(hypot(back-p) >= fb).
+ * xy_back may be NULL.  n_steps_out (optional) receives the number of lk_step evaluations executed. */
+int sfmx_klt_track(sfmx_ctx* ctx, const sfmx_pyramid* pyr_a, const sfmx_pyramid* pyr_b,
+                   const double* xy_in, int n, const sfmx_klt_cfg* cfg, double* xy_fwd,
+                   double* xy_back, uint8_t* keep, uint64_t* n_steps_out);
+
+/* ---- RANSAC scoring: replaces the hypothesis loop of find_E_ransac (T:664-677) --------------- */
+/* xi,xj: K^-1-normalised correspondences [n][2]; idx8: pre-drawn sample octets [H][8] (the
+ * caller draws them with the libstdc++-compatible generator so the stream matches T:657-665).
+ * The device builds every 8-point hypothesis (A6-A11), scores all n points per hypothesis with the
+ * Sampson error (T:629-638) and counts err < thr.  counts_out [H] (optional) receives every count;
+ * best_iter/best_count = argmax with the LOWEST iteration on ties (the reference's strict '>').
+ * E_out [H][9] (optional) receives the device hypotheses. */
+int sfmx_ransac_score(sfmx_ctx* ctx, const double* xi, const double* xj, int n, const int32_t* idx8,
+                      int H, double thr, int32_t* counts_out, int32_t* best_iter, int32_t* best_count,
+                      double* E_out);
+/* inlier mask of ONE essential matrix (used for the winner after the host has re-derived its E
+ * with the platform libm, so the mask and E are bit-identical to the reference's) */
+int sfmx_sampson_mask(sfmx_ctx* ctx, const double* xi, const double* xj, int n, const double* E9,
+                      double thr, uint8_t* mask_out, int32_t* count_out);
+
+/* ---- local BA: replaces the S,b build of bundle_adjust_window (T:893-1071) ------------------ */
+/* poses_wc [W][12] = world->camera (R row-major, t); X [P][3]; CSR observations: obs_ptr [P+1],
+ * obs_li [R] window-local pose index, obs_uv [R][2] pixels.  Points are consumed in array order
+ * (the caller passes them in the reference's unordered_map iteration order).
+ * Output: S [6W][6W] row-major and b [6W] AFTER damping (+lambda on the diagonal) and gauge
+ * (+1e9 on DoF 0..5, b[0..5] = 0) when damp != 0.  Accumulation order is the reference's, so S,b
+ * are bit-identical on one GPU. */
+typedef struct sfmx_ba_problem sfmx_ba_problem;
+int sfmx_ba_create(sfmx_ctx* ctx, int W, int P, const double* X, const int32_t* obs_ptr,
+                   const int32_t* obs_li, const double* obs_uv, sfmx_ba_problem** out);
+void sfmx_ba_destroy(sfmx_ctx* ctx, sfmx_ba_problem* prob);
+int sfmx_ba_build(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, double fx, double fy,
+                  double cx, double cy, double huber, double lambda, int damp, double* S_out,
+                  double* b_out);
+/* build + solve on the device in one submission: dx [6W]; returns SFMX_ERR_SINGULAR where the
+ * reference's solve_gauss would throw (the caller then skips BA as T:1076-1078 does). */
+int sfmx_ba_step(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, double fx, double fy,
+                 double cx, double cy, double huber, double lambda, double* dx_out);
+/* partial sums for point-sharded multi-GPU BA: raw S,b of this problem's points only (no damping);
+ * device pointers (valid until the next call on prob) so the caller can all-reduce them in HBM. */
+int sfmx_ba_build_partial(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, double fx,
+                          double fy, double cx, double cy, double huber, void** S_dev, void** b_dev);
+
+/* ---- dense solve: replaces sfm::solve_gauss (cpp/include/dense.hpp:54-93) -------------------- */
+/* Gaussian elimination with partial pivoting in the reference's operation order; A [n][n]
+ * row-major and b [n] are not modified; x [n].  SFMX_ERR_SINGULAR when a pivot is < 1e-15. */
+int sfmx_solve_dense(sfmx_ctx* ctx, const double* A, const double* b, int n, double* x);
+
+/* ---- self-check hooks used by the parity tests (device arithmetic vs the host libm) ---------- */
+int sfmx_debug_hypot(sfmx_ctx* ctx, const double* x, const double* y, int n, double* out);
+int sfmx_debug_divsqrt(sfmx_ctx* ctx, const double* x, const double* y, int n, double* div_out,
+                       double* sqrt_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFMX_H */

@@ -1,0 +1,259 @@
+"""ctypes binding of include/sfmx.h (libsfmx.so) — plumbing for tests and bench.py.
+
+There is NO fallback: if the library is missing or no gfx950 device can be opened, every entry
+point raises ``SfmxError``.  Nothing here computes anything on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_uint8, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libsfmx.so")
+
+SFMX_OK, SFMX_ERR_INVALID, SFMX_ERR_HIP, SFMX_ERR_NO_DEVICE, SFMX_ERR_SINGULAR, SFMX_ERR_UNSUPPORTED = range(6)
+
+# every symbol include/sfmx.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "sfmx_ctx_create", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_stream", "sfmx_set_timing",
+    "sfmx_last_kernel_us", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
+    "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
+    "sfmx_shi_tomasi_candidates", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",
+    "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
+    "sfmx_debug_hypot", "sfmx_debug_divsqrt",
+]
+
+
+class SfmxError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"sfmx status {status}: {msg}")
+        self.status = status
+
+
+class KltCfg(ctypes.Structure):
+    _fields_ = [("levels", c_int), ("win_radius", c_int), ("iters", c_int), ("fb_thresh", c_double)]
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SfmxError(SFMX_ERR_NO_DEVICE, f"{LIB_PATH} not built: run __graft_entry__.build() (hipcc, gfx950)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.sfmx_last_error.restype = c_char_p
+        _lib.sfmx_last_kernel_us.restype = c_double
+        _lib.sfmx_stream.restype = c_void_p
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(POINTER(t))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Pyramid:
+    def __init__(self, ctx: "Context", w: int, h: int, levels: int):
+        self.ctx, self.w, self.h, self.levels = ctx, w, h, levels
+        self.h_ = c_void_p()
+        ctx._chk(ctx.lib.sfmx_pyramid_create(ctx.h_, c_int(w), c_int(h), c_int(levels), byref(self.h_)))
+
+    def upload(self, img: np.ndarray):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.h, self.w)
+        self.ctx._chk(self.ctx.lib.sfmx_pyramid_upload(self.ctx.h_, self.h_, _p(img, c_uint8)))
+        return self
+
+    def set_device(self, dev_ptr: int):
+        self.ctx._chk(self.ctx.lib.sfmx_pyramid_set_device(self.ctx.h_, self.h_, c_void_p(dev_ptr)))
+        return self
+
+    def level(self, l: int) -> np.ndarray:
+        w, h = c_int(), c_int()
+        self.ctx._chk(self.ctx.lib.sfmx_pyramid_level_size(self.h_, c_int(l), byref(w), byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.ctx._chk(self.ctx.lib.sfmx_pyramid_download_level(self.ctx.h_, self.h_, c_int(l), _p(out, c_uint8)))
+        return out
+
+    def close(self):
+        if self.h_:
+            self.ctx.lib.sfmx_pyramid_destroy(self.ctx.h_, self.h_)
+            self.h_ = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BaProblem:
+    def __init__(self, ctx: "Context", W: int, X, obs_ptr, obs_li, obs_uv):
+        self.ctx, self.W = ctx, W
+        X = _f64(X)
+        obs_ptr = np.ascontiguousarray(obs_ptr, np.int32)
+        obs_li = np.ascontiguousarray(obs_li, np.int32)
+        obs_uv = _f64(obs_uv)
+        self.P = X.shape[0]
+        self.h_ = c_void_p()
+        ctx._chk(ctx.lib.sfmx_ba_create(ctx.h_, c_int(W), c_int(self.P), _p(X, c_double), _p(obs_ptr, c_int32),
+                                        _p(obs_li, c_int32), _p(obs_uv, c_double), byref(self.h_)))
+
+    def build(self, poses_wc, fx, fy, cx, cy, huber, lam, damp=True):
+        D = 6 * self.W
+        poses = _f64(poses_wc)
+        S = np.zeros((D, D))
+        b = np.zeros(D)
+        self.ctx._chk(self.ctx.lib.sfmx_ba_build(self.ctx.h_, self.h_, _p(poses, c_double), c_double(fx), c_double(fy),
+                                                 c_double(cx), c_double(cy), c_double(huber), c_double(lam),
+                                                 c_int(1 if damp else 0), _p(S, c_double), _p(b, c_double)))
+        return S, b
+
+    def step(self, poses_wc, fx, fy, cx, cy, huber, lam):
+        """returns (status, dx): status SFMX_OK or SFMX_ERR_SINGULAR"""
+        poses = _f64(poses_wc)
+        dx = np.zeros(6 * self.W)
+        rc = self.ctx.lib.sfmx_ba_step(self.ctx.h_, self.h_, _p(poses, c_double), c_double(fx), c_double(fy), c_double(cx),
+                                       c_double(cy), c_double(huber), c_double(lam), _p(dx, c_double))
+        if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
+            self.ctx._chk(rc)
+        return rc, dx
+
+    def build_partial(self, poses_wc, fx, fy, cx, cy, huber):
+        """device pointers (S, b) of this shard's raw sums — for RCCL all-reduce by the caller"""
+        poses = _f64(poses_wc)
+        S, b = c_void_p(), c_void_p()
+        self.ctx._chk(self.ctx.lib.sfmx_ba_build_partial(self.ctx.h_, self.h_, _p(poses, c_double), c_double(fx), c_double(fy),
+                                                         c_double(cx), c_double(cy), c_double(huber), byref(S), byref(b)))
+        return S.value, b.value
+
+    def close(self):
+        if self.h_:
+            self.ctx.lib.sfmx_ba_destroy(self.ctx.h_, self.h_)
+            self.h_ = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.h_ = c_void_p()
+        rc = self.lib.sfmx_ctx_create(c_int(device), byref(self.h_))
+        if rc != SFMX_OK:
+            raise SfmxError(rc, "sfmx_ctx_create failed: no usable MI355X (gfx950) device — there is no CPU fallback")
+
+    def _chk(self, rc: int):
+        if rc != SFMX_OK:
+            raise SfmxError(rc, (self.lib.sfmx_last_error(self.h_) or b"").decode())
+
+    def close(self):
+        if self.h_:
+            self.lib.sfmx_ctx_destroy(self.h_)
+            self.h_ = c_void_p()
+
+    def set_timing(self, on: bool):
+        self._chk(self.lib.sfmx_set_timing(self.h_, c_int(1 if on else 0)))
+
+    def last_kernel_us(self) -> float:
+        return float(self.lib.sfmx_last_kernel_us(self.h_))
+
+    def sync(self):
+        self._chk(self.lib.sfmx_sync(self.h_))
+
+    def pyramid(self, img: np.ndarray, levels: int) -> Pyramid:
+        h, w = img.shape
+        return Pyramid(self, w, h, levels).upload(img)
+
+    def shi_score(self, pyr: Pyramid):
+        score = np.zeros((pyr.h, pyr.w))
+        mx = c_double()
+        self._chk(self.lib.sfmx_shi_tomasi_score(self.h_, pyr.h_, _p(score, c_double), byref(mx)))
+        return score, mx.value
+
+    def shi_candidates(self, pyr: Pyramid, quality: float, cap: int | None = None):
+        cap = cap or pyr.w * pyr.h
+        xy = np.zeros(cap, np.uint32)
+        sc = np.zeros(cap)
+        n = c_int()
+        mx = c_double()
+        self._chk(self.lib.sfmx_shi_tomasi_candidates(self.h_, pyr.h_, c_double(quality), c_int(cap), _p(xy, c_uint32),
+                                                      _p(sc, c_double), byref(n), byref(mx)))
+        m = min(n.value, cap)
+        return (xy[:m] & 0xFFFF).astype(np.int32), (xy[:m] >> 16).astype(np.int32), sc[:m].copy(), n.value, mx.value
+
+    def klt_track(self, pa: Pyramid, pb: Pyramid, xy, levels=3, radius=5, iters=10, fb=1.0):
+        xy = _f64(xy).reshape(-1, 2)
+        n = xy.shape[0]
+        fwd = np.zeros((n, 2))
+        back = np.zeros((n, 2))
+        keep = np.zeros(n, np.uint8)
+        steps = c_uint64()
+        cfg = KltCfg(levels, radius, iters, fb)
+        self._chk(self.lib.sfmx_klt_track(self.h_, pa.h_, pb.h_, _p(xy, c_double), c_int(n), byref(cfg), _p(fwd, c_double),
+                                          _p(back, c_double), _p(keep, c_uint8), byref(steps)))
+        return fwd, back, keep, steps.value
+
+    def ransac_score(self, xi, xj, idx8, thr, want_E=False):
+        xi, xj = _f64(xi), _f64(xj)
+        idx8 = np.ascontiguousarray(idx8, np.int32)
+        H = idx8.shape[0]
+        counts = np.zeros(H, np.int32)
+        bi, bc = c_int32(), c_int32()
+        E = np.zeros((H, 3, 3)) if want_E else None
+        self._chk(self.lib.sfmx_ransac_score(self.h_, _p(xi, c_double), _p(xj, c_double), c_int(xi.shape[0]), _p(idx8, c_int32),
+                                             c_int(H), c_double(thr), _p(counts, c_int32), byref(bi), byref(bc),
+                                             _p(E, c_double) if want_E else None))
+        return counts, bi.value, bc.value, E
+
+    def sampson_mask(self, xi, xj, E, thr):
+        xi, xj, E = _f64(xi), _f64(xj), _f64(E)
+        n = xi.shape[0]
+        mask = np.zeros(n, np.uint8)
+        cnt = c_int32()
+        self._chk(self.lib.sfmx_sampson_mask(self.h_, _p(xi, c_double), _p(xj, c_double), c_int(n), _p(E, c_double), c_double(thr),
+                                             _p(mask, c_uint8), byref(cnt)))
+        return mask, cnt.value
+
+    def ba_problem(self, W, X, obs_ptr, obs_li, obs_uv) -> BaProblem:
+        return BaProblem(self, W, X, obs_ptr, obs_li, obs_uv)
+
+    def solve_dense(self, A, b):
+        A, b = _f64(A), _f64(b)
+        n = b.shape[0]
+        x = np.zeros(n)
+        rc = self.lib.sfmx_solve_dense(self.h_, _p(A, c_double), _p(b, c_double), c_int(n), _p(x, c_double))
+        if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
+            self._chk(rc)
+        return rc, x
+
+    def debug_hypot(self, x, y):
+        x, y = _f64(x), _f64(y)
+        out = np.zeros_like(x)
+        self._chk(self.lib.sfmx_debug_hypot(self.h_, _p(x, c_double), _p(y, c_double), c_int(x.size), _p(out, c_double)))
+        return out
+
+    def debug_divsqrt(self, x, y):
+        x, y = _f64(x), _f64(y)
+        d, s = np.zeros_like(x), np.zeros_like(x)
+        self._chk(self.lib.sfmx_debug_divsqrt(self.h_, _p(x, c_double), _p(y, c_double), c_int(x.size), _p(d, c_double),
+                                              _p(s, c_double)))
+        return d, s
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

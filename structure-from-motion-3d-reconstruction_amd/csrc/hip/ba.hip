@@ -1,0 +1,476 @@
+// ba.hip — local bundle adjustment: reduced camera system build (T:893-1071) and dense solve
+// (cpp/include/dense.hpp:54-93) for gfx950.
+//
+// The reference accumulates S (6W x 6W) and b point after point, so every element of S,b is an
+// ORDERED floating-point sum over the points; parity is bit-exact, so the order is kept:
+//
+//  k_ba_points  (parallel over points, one lane per point): residuals, analytic Jacobians, Huber
+//      weights, per-point Hpp/bp and per-(point,pose) Hxx/bx/Hxp exactly as T:920-1009, then
+//      inv3(Hpp) and G = Hxp * Hpp^-1, G*bp (T:1011-1041).  Output is one compact RECORD per point
+//      (84 doubles per observing pose) plus a pose->slot table; poses (W x 12 doubles) sit in LDS.
+//  k_ba_reduce  (one lane per element of S and b): walks the records in point order and performs the
+//      reference's additions in the reference's sequence (T:1015-1057): Hxx first, then the Schur
+//      term G_a * Hxp_b^T (which the reference ADDS, quirk Q6), bx then -G*bp for b; finally the
+//      damping and gauge terms (T:1064-1071).  Loads are issued 8 points ahead of the dependent
+//      add chain, which is the only serial part.
+//  k_solve_gauss (one workgroup, matrix in LDS): partial-pivoting elimination with the reference's
+//      first-maximum pivot rule, row normalisation, |f| < 1e-18 skip and ascending back-substitution.
+//
+// Algorithmic bytes per BA iteration: 20*R + 24*P + 96*W read, 8*(D^2+D) written.
+#include "sfmx_internal.h"
+
+#define BA_SLOT 84  // doubles per (point, pose) slot: Hxx 36 | bx 6 | Hxp 18 | G 18 | G*bp 6
+#define BA_MAX_OBS 16
+#define BA_MAX_W 64
+
+struct sfmx_ba_problem {
+  int W = 0, P = 0, R = 0, MS = 0;
+  double* X = nullptr;
+  int32_t* obs_ptr = nullptr;
+  int32_t* obs_li = nullptr;
+  double* obs_uv = nullptr;
+  double* poses = nullptr;    // [W][12]
+  double* rec = nullptr;      // [P][MS][BA_SLOT]
+  int8_t* slot_of = nullptr;  // [P][W]  (-1: pose does not see the point / point skipped)
+  double* S = nullptr;        // [D*D]
+  double* b = nullptr;        // [D]
+  double* work = nullptr;     // solve scratch: dx [D] + status
+};
+
+// dense.hpp:96-119
+__device__ __forceinline__ bool inv3_ref(const double* A, double* inv) {
+  const double a = A[0], b = A[1], c = A[2], d = A[3], e = A[4], f = A[5], g = A[6], h = A[7], i = A[8];
+  const double c11 = (e * i - f * h), c12 = -(d * i - f * g), c13 = (d * h - e * g);
+  const double c21 = -(b * i - c * h), c22 = (a * i - c * g), c23 = -(a * h - b * g);
+  const double c31 = (b * f - c * e), c32 = -(a * f - c * d), c33 = (a * e - b * d);
+  const double det = a * c11 + b * c12 + c * c13;
+  if (fabs(det) < 1e-15) return false;
+  const double r = 1.0 / det;
+  inv[0] = c11 * r; inv[1] = c21 * r; inv[2] = c31 * r;
+  inv[3] = c12 * r; inv[4] = c22 * r; inv[5] = c32 * r;
+  inv[6] = c13 * r; inv[7] = c23 * r; inv[8] = c33 * r;
+  return true;
+}
+
+__global__ __launch_bounds__(64) void k_ba_points(int W, int P, int MS, const double* __restrict__ poses, const double* __restrict__ X,
+                                                  const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
+                                                  const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
+                                                  double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of) {
+  __shared__ double sp[BA_MAX_W * 12];
+  for (int i = threadIdx.x; i < W * 12; i += blockDim.x) sp[i] = poses[i];
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int8_t* so = slot_of + (size_t)p * W;
+  for (int i = 0; i < W; i++) so[i] = -1;
+  const int o0 = obs_ptr[p], o1 = obs_ptr[p + 1];
+  if (o1 - o0 > BA_MAX_OBS) return;  // T:915-918
+  double* prec = rec + (size_t)p * MS * BA_SLOT;
+  const double Xx = X[3 * p], Xy = X[3 * p + 1], Xz = X[3 * p + 2];
+  double Hpp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, bp[3] = {0, 0, 0};
+  int na = 0;
+  for (int o = o0; o < o1; ++o) {
+    const int li = obs_li[o];
+    if (li < 0 || li >= W) continue;  // malformed input: ignore (cannot occur through the host API)
+    int ai = so[li];
+    if (ai < 0) {
+      ai = na++;
+      so[li] = (int8_t)ai;
+      double* z = prec + (size_t)ai * BA_SLOT;
+      for (int k = 0; k < 60; k++) z[k] = 0.0;
+    }
+    const double* R = sp + 12 * li;
+    const double Xcx = (R[0] * Xx + R[1] * Xy + R[2] * Xz) + R[9];
+    const double Xcy = (R[3] * Xx + R[4] * Xy + R[5] * Xz) + R[10];
+    const double Xcz = (R[6] * Xx + R[7] * Xy + R[8] * Xz) + R[11];
+    if (Xcz <= 1e-6) continue;  // T:933 (NaN passes, as in the reference)
+    const double qx = Xcx / Xcz, qy = Xcy / Xcz;
+    const double rx = obs_uv[2 * o] - (fx * qx + cx);
+    const double ry = obs_uv[2 * o + 1] - (fy * qy + cy);
+    const double rn = sfmx::hypot_glibc(rx, ry);
+    const double wgt = (rn <= huber) ? 1.0 : huber / (rn + 1e-12);
+    const double iz = 1.0 / Xcz, iz2 = iz * iz;
+    double Jq[6];
+    Jq[0] = fx * iz; Jq[1] = 0.0; Jq[2] = -fx * Xcx * iz2;
+    Jq[3] = 0.0; Jq[4] = fy * iz; Jq[5] = -fy * Xcy * iz2;
+    double Jp[6], Jr[6];
+#pragma unroll
+    for (int row = 0; row < 2; ++row)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double a0 = Jq[row * 3 + 0] * R[c], a1 = Jq[row * 3 + 1] * R[3 + c], a2 = Jq[row * 3 + 2] * R[6 + c];
+        Jp[row * 3 + c] = a0 + a1 + a2;
+      }
+    const double Xm[9] = {0.0, -Xcz, Xcy, Xcz, 0.0, -Xcx, -Xcy, Xcx, 0.0};
+#pragma unroll
+    for (int row = 0; row < 2; ++row)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double a0 = -Jq[row * 3 + 0] * Xm[c], a1 = -Jq[row * 3 + 1] * Xm[3 + c], a2 = -Jq[row * 3 + 2] * Xm[6 + c];
+        Jr[row * 3 + c] = a0 + a1 + a2;
+      }
+    const double Jx[12] = {Jr[0], Jr[1], Jr[2], Jq[0], Jq[1], Jq[2], Jr[3], Jr[4], Jr[5], Jq[3], Jq[4], Jq[5]};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double s = 0.0;
+        s += Jp[a] * Jp[c];
+        s += Jp[3 + a] * Jp[3 + c];
+        Hpp[a * 3 + c] += wgt * s;
+      }
+      double sb = 0.0;
+      sb += Jp[a] * rx;
+      sb += Jp[3 + a] * ry;
+      bp[a] += wgt * sb;
+    }
+    double* A = prec + (size_t)ai * BA_SLOT;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        double s = 0.0;
+        s += Jx[a] * Jx[c];
+        s += Jx[6 + a] * Jx[6 + c];
+        A[a * 6 + c] += wgt * s;
+      }
+      double sb = 0.0;
+      sb += Jx[a] * rx;
+      sb += Jx[6 + a] * ry;
+      A[36 + a] += wgt * sb;
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double s = 0.0;
+        s += Jx[a] * Jp[c];
+        s += Jx[6 + a] * Jp[3 + c];
+        A[42 + a * 3 + c] += wgt * s;
+      }
+  }
+  double iH[9];
+  if (!inv3_ref(Hpp, iH)) {  // T:1012: the point contributes nothing at all
+    for (int i = 0; i < W; i++) so[i] = -1;
+    return;
+  }
+  for (int k = 0; k < na; k++) {
+    double* A = prec + (size_t)k * BA_SLOT;
+    const double* Hxp = A + 42;
+    double* G = A + 60;
+    double* gb = A + 78;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      const double h0 = Hxp[r * 3 + 0], h1 = Hxp[r * 3 + 1], h2 = Hxp[r * 3 + 2];
+      const double g0 = h0 * iH[0] + h1 * iH[3] + h2 * iH[6];
+      const double g1 = h0 * iH[1] + h1 * iH[4] + h2 * iH[7];
+      const double g2 = h0 * iH[2] + h1 * iH[5] + h2 * iH[8];
+      G[r * 3 + 0] = g0; G[r * 3 + 1] = g1; G[r * 3 + 2] = g2;
+      gb[r] = g0 * bp[0] + g1 * bp[1] + g2 * bp[2];
+    }
+  }
+}
+
+#define BA_AHEAD 8
+__global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
+                                                   double lambda, int damp, double* __restrict__ S, double* __restrict__ b) {
+  const int D = 6 * W;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= D * D + D) return;
+  const bool is_b = e >= D * D;
+  const int i = is_b ? e - D * D : e / D;
+  const int j = is_b ? 0 : e % D;
+  const int A = i / 6, r = i % 6, B = is_b ? A : j / 6, cc = j % 6;
+  const bool diag_blk = (!is_b) && (A == B);
+  const size_t pstride = (size_t)MS * BA_SLOT;
+  double acc = 0.0;
+  for (int p0 = 0; p0 < P; p0 += BA_AHEAD) {
+    int sa[BA_AHEAD], sb[BA_AHEAD];
+    double v0[BA_AHEAD], g0[BA_AHEAD], g1[BA_AHEAD], g2[BA_AHEAD], h0[BA_AHEAD], h1[BA_AHEAD], h2[BA_AHEAD];
+#pragma unroll
+    for (int u = 0; u < BA_AHEAD; u++) {
+      const int p = min(p0 + u, P - 1);
+      const bool ok = (p0 + u) < P;
+      const int a = slot_of[(size_t)p * W + A], bb = slot_of[(size_t)p * W + B];
+      sa[u] = ok ? a : -1;
+      sb[u] = ok ? bb : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < BA_AHEAD; u++) {
+      const int p = min(p0 + u, P - 1);
+      const double* base = rec + (size_t)p * pstride;
+      const double* ra = base + (size_t)max(sa[u], 0) * BA_SLOT;
+      const double* rb = base + (size_t)max(sb[u], 0) * BA_SLOT;
+      if (is_b) {
+        v0[u] = ra[36 + r];
+        g0[u] = ra[78 + r];
+        g1[u] = g2[u] = h0[u] = h1[u] = h2[u] = 0.0;
+      } else {
+        v0[u] = ra[r * 6 + cc];
+        g0[u] = ra[60 + r * 3 + 0]; g1[u] = ra[60 + r * 3 + 1]; g2[u] = ra[60 + r * 3 + 2];
+        h0[u] = rb[42 + cc * 3 + 0]; h1[u] = rb[42 + cc * 3 + 1]; h2[u] = rb[42 + cc * 3 + 2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BA_AHEAD; u++) {
+      if (is_b) {
+        if (sa[u] >= 0) {
+          acc += v0[u];  // b[li] += bx      (T:1018)
+          acc -= g0[u];  // b[li] -= G*bp    (T:1041)
+        }
+      } else {
+        if (diag_blk && sa[u] >= 0) acc += v0[u];                                          // S += Hxx         (T:1017)
+        if (sa[u] >= 0 && sb[u] >= 0) acc += g0[u] * h0[u] + g1[u] * h1[u] + g2[u] * h2[u];  // S += G_a Hxp_b^T (T:1055)
+      }
+    }
+  }
+  if (is_b) {
+    if (damp && i < 6) acc = 0.0;  // T:1070
+    b[i] = acc;
+  } else {
+    if (damp && i == j) {
+      acc += lambda;            // T:1064
+      if (i < 6) acc += 1e9;    // T:1069
+    }
+    S[(size_t)i * D + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dense solve
+// status[0] = 0 ok, 1 singular (pivot < 1e-15).  A,b are read from global memory, x written.
+__global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ Ain, const double* __restrict__ bin, int n,
+                                                     double* __restrict__ x, int* __restrict__ status) {
+  extern __shared__ __align__(16) double sm[];
+  const int ld = n + 1;  // row stride (odd multiple of 8 B keeps column walks off one bank)
+  double* A = sm;                 // [n][ld]
+  double* bb = A + (size_t)n * ld;  // [n]
+  double* fcol = bb + n;          // [n]
+  __shared__ double red_v[4];
+  __shared__ int red_i[4];
+  __shared__ int s_piv, s_stop;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int e = tid; e < n * n; e += nt) A[(size_t)(e / n) * ld + (e % n)] = Ain[e];
+  for (int e = tid; e < n; e += nt) bb[e] = bin[e];
+  if (tid == 0) s_stop = 0;
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    // ---- pivot: first strictly-largest |A[i][k]|, i >= k (dense.hpp:61-66)
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    for (int i = k + tid; i < n; i += nt) {
+      const double v = fabs(A[(size_t)i * ld + k]);
+      if (v > bv) { bv = v; bi = i; }  // NaN never wins
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_down(bv, o, 64);
+      const int oi = __shfl_down(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      double v = red_v[0];
+      int ix = red_i[0];
+      for (int w = 1; w < (nt >> 6); w++)
+        if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+      const double akk0 = fabs(A[(size_t)k * ld + k]);
+      int piv = ix;
+      double best = v;
+      if (akk0 != akk0) { piv = k; best = akk0; }       // NaN on the diagonal: `v > best` is never true
+      else if (piv == 0x7fffffff) { piv = k; best = akk0; }
+      s_piv = piv;
+      if (best < 1e-15) s_stop = 1;                      // dense.hpp:67 throws
+    }
+    __syncthreads();
+    if (s_stop) {
+      if (tid == 0) status[0] = 1;
+      return;
+    }
+    const int piv = s_piv;
+    if (piv != k) {
+      for (int j = k + tid; j < n; j += nt) {
+        const double t = A[(size_t)k * ld + j];
+        A[(size_t)k * ld + j] = A[(size_t)piv * ld + j];
+        A[(size_t)piv * ld + j] = t;
+      }
+      if (tid == 0) { const double t = bb[k]; bb[k] = bb[piv]; bb[piv] = t; }
+    }
+    __syncthreads();
+    const double akk = A[(size_t)k * ld + k];
+    __syncthreads();
+    for (int j = k + tid; j < n; j += nt) A[(size_t)k * ld + j] /= akk;
+    if (tid == 0) bb[k] /= akk;
+    for (int i = k + 1 + tid; i < n; i += nt) fcol[i] = A[(size_t)i * ld + k];
+    __syncthreads();
+    // ---- eliminate rows below (dense.hpp:78-83); rows with |f| < 1e-18 are skipped
+    const int cols = n - k, rows = n - k - 1;
+    for (int e = tid; e < rows * cols; e += nt) {
+      const int i = k + 1 + e / cols, j = k + e % cols;
+      const double f = fcol[i];
+      if (fabs(f) < 1e-18) continue;
+      A[(size_t)i * ld + j] -= f * A[(size_t)k * ld + j];
+    }
+    for (int i = k + 1 + tid; i < n; i += nt) {
+      const double f = fcol[i];
+      if (fabs(f) < 1e-18) continue;
+      bb[i] -= f * bb[k];
+    }
+    __syncthreads();
+  }
+  // ---- back substitution, ascending j per row (dense.hpp:86-91): inherently serial
+  if (tid == 0) {
+    for (int i = n - 1; i >= 0; i--) {
+      double s = bb[i];
+      for (int j = i + 1; j < n; j++) s -= A[(size_t)i * ld + j] * fcol[j];
+      fcol[i] = s;
+    }
+    status[0] = 0;
+  }
+  __syncthreads();
+  for (int e = tid; e < n; e += nt) x[e] = fcol[e];
+}
+
+static size_t solve_shmem(int n) { return ((size_t)n * (n + 1) + 2 * (size_t)n) * sizeof(double); }
+#define SOLVE_MAX_N 136
+
+static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    SFMX_HIP(c, hipFuncSetAttribute((const void*)k_solve_gauss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem(SOLVE_MAX_N)));
+    attr_set = true;
+  }
+  k_solve_gauss<<<1, 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus);
+  SFMX_HIP(c, hipGetLastError());
+  return SFMX_OK;
+}
+
+static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
+                           double huber, double lambda, int damp, KernelTimer& t) {
+  SFMX_HIP(c, hipMemcpyAsync(q->poses, poses_wc, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
+  const int D = 6 * q->W;
+  t.start();
+  k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, q->poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy,
+                                                    huber, q->rec, q->slot_of);
+  k_ba_reduce<<<(D * D + D + 255) / 256, 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, lambda, damp, q->S, q->b);
+  t.stop();
+  SFMX_HIP(c, hipGetLastError());
+  return SFMX_OK;
+}
+
+extern "C" {
+
+int sfmx_ba_create(sfmx_ctx* c, int W, int P, const double* X, const int32_t* obs_ptr, const int32_t* obs_li, const double* obs_uv,
+                   sfmx_ba_problem** out) {
+  SFMX_REQUIRE(c, c && out && W >= 1 && W <= BA_MAX_W && P >= 1 && X && obs_ptr && obs_li && obs_uv);
+  const int R = obs_ptr[P];
+  SFMX_REQUIRE(c, R >= 0 && obs_ptr[0] == 0);
+  sfmx_ba_problem* q = new sfmx_ba_problem;
+  q->W = W; q->P = P; q->R = R;
+  q->MS = W < BA_MAX_OBS ? W : BA_MAX_OBS;
+  const int D = 6 * W;
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n ? n : 8); };
+  alloc((void**)&q->X, (size_t)P * 24);
+  alloc((void**)&q->obs_ptr, (size_t)(P + 1) * 4);
+  alloc((void**)&q->obs_li, (size_t)R * 4);
+  alloc((void**)&q->obs_uv, (size_t)R * 16);
+  alloc((void**)&q->poses, (size_t)W * 96);
+  alloc((void**)&q->rec, (size_t)P * q->MS * BA_SLOT * 8);
+  alloc((void**)&q->slot_of, (size_t)P * W);
+  alloc((void**)&q->S, (size_t)D * D * 8);
+  alloc((void**)&q->b, (size_t)D * 8);
+  alloc((void**)&q->work, (size_t)D * 8 + 64);
+  if (e != hipSuccess) {
+    sfmx_ba_destroy(c, q);
+    return sfmx_fail(c, SFMX_ERR_HIP, "hipMalloc(ba problem)", e);
+  }
+  *out = q;
+  SFMX_HIP(c, hipMemcpyAsync(q->X, X, (size_t)P * 24, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(q->obs_ptr, obs_ptr, (size_t)(P + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if (R > 0) {
+    SFMX_HIP(c, hipMemcpyAsync(q->obs_li, obs_li, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
+    SFMX_HIP(c, hipMemcpyAsync(q->obs_uv, obs_uv, (size_t)R * 16, hipMemcpyHostToDevice, c->stream));
+  }
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));  // caller buffers may be released on return
+  return SFMX_OK;
+}
+
+void sfmx_ba_destroy(sfmx_ctx* c, sfmx_ba_problem* q) {
+  if (!q) return;
+  if (c) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {q->X, q->obs_ptr, q->obs_li, q->obs_uv, q->poses, q->rec, q->slot_of, q->S, q->b, q->work};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete q;
+}
+
+int sfmx_ba_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy, double huber,
+                  double lambda, int damp, double* S_out, double* b_out) {
+  SFMX_REQUIRE(c, c && q && poses_wc && S_out && b_out);
+  KernelTimer t(c);
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, damp, t);
+  if (rc) return rc;
+  const int D = 6 * q->W;
+  SFMX_HIP(c, hipMemcpyAsync(S_out, q->S, (size_t)D * D * 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(b_out, q->b, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  t.collect();
+  return SFMX_OK;
+}
+
+int sfmx_ba_build_partial(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
+                          double huber, void** S_dev, void** b_dev) {
+  SFMX_REQUIRE(c, c && q && poses_wc && S_dev && b_dev);
+  KernelTimer t(c);
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, 0.0, 0, t);
+  if (rc) return rc;
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  t.collect();
+  *S_dev = q->S;
+  *b_dev = q->b;
+  return SFMX_OK;
+}
+
+int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy, double huber,
+                 double lambda, double* dx_out) {
+  SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
+  const int D = 6 * q->W;
+  SFMX_REQUIRE(c, D <= SOLVE_MAX_N);
+  KernelTimer t(c);
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t);
+  if (rc) return rc;
+  int* dstatus = reinterpret_cast<int*>(q->work + D);
+  rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
+  if (rc) return rc;
+  int status = 0;
+  SFMX_HIP(c, hipMemcpyAsync(dx_out, q->work, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&status, dstatus, 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  t.collect();
+  return status ? SFMX_ERR_SINGULAR : SFMX_OK;
+}
+
+int sfmx_solve_dense(sfmx_ctx* c, const double* A, const double* b, int n, double* x) {
+  SFMX_REQUIRE(c, c && A && b && x && n >= 1);
+  if (n > SOLVE_MAX_N) return sfmx_fail(c, SFMX_ERR_UNSUPPORTED, "sfmx_solve_dense: n > 136 (LDS-resident solver)", hipSuccess);
+  const size_t nb = (size_t)n * n * 8;
+  SFMX_HIP(c, c->d[0].ensure(nb));
+  SFMX_HIP(c, c->d[1].ensure((size_t)n * 8));
+  SFMX_HIP(c, c->d[2].ensure((size_t)n * 8 + 64));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, A, nb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, b, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  int* dstatus = reinterpret_cast<int*>(c->d[2].as<double>() + n);
+  KernelTimer t(c);
+  t.start();
+  int rc = launch_solve(c, c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[2].as<double>(), dstatus);
+  t.stop();
+  if (rc) return rc;
+  int status = 0;
+  SFMX_HIP(c, hipMemcpyAsync(x, c->d[2].p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&status, dstatus, 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  t.collect();
+  return status ? SFMX_ERR_SINGULAR : SFMX_OK;
+}
+
+}  // extern "C"

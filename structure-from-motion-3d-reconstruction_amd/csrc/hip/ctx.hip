@@ -1,0 +1,108 @@
+// ctx.hip — context lifetime, error strings, debug hooks.
+#include "sfmx_internal.h"
+
+int sfmx_fail(sfmx_ctx* ctx, int status, const char* what, hipError_t e) {
+  if (ctx) {
+    ctx->err = what ? what : "";
+    if (e != hipSuccess) {
+      ctx->err += ": ";
+      ctx->err += hipGetErrorString(e);
+    }
+  }
+  return status;
+}
+
+extern "C" {
+
+int sfmx_ctx_create(int device_id, sfmx_ctx** out) {
+  if (!out) return SFMX_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return SFMX_ERR_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return SFMX_ERR_NO_DEVICE;
+  sfmx_ctx* c = new sfmx_ctx;
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return SFMX_ERR_HIP;
+  }
+  *out = c;
+  return SFMX_OK;
+}
+
+void sfmx_ctx_destroy(sfmx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& b : c->d) b.release();
+  for (auto& b : c->h) b.release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* sfmx_last_error(const sfmx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int sfmx_sync(sfmx_ctx* c) {
+  if (!c) return SFMX_ERR_INVALID;
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  return SFMX_OK;
+}
+void* sfmx_stream(sfmx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+int sfmx_set_timing(sfmx_ctx* c, int enabled) {
+  if (!c) return SFMX_ERR_INVALID;
+  c->timing = enabled != 0;
+  return SFMX_OK;
+}
+double sfmx_last_kernel_us(const sfmx_ctx* c) { return c ? c->last_us : 0.0; }
+
+}  // extern "C"
+
+// ---- device arithmetic self-checks -------------------------------------------------------------
+__global__ void k_debug_hypot(const double* x, const double* y, int n, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = sfmx::hypot_glibc(x[i], y[i]);
+}
+__global__ void k_debug_divsqrt(const double* x, const double* y, int n, double* d, double* s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    d[i] = x[i] / y[i];
+    s[i] = sqrt(fabs(x[i]));
+  }
+}
+
+extern "C" {
+
+int sfmx_debug_hypot(sfmx_ctx* c, const double* x, const double* y, int n, double* out) {
+  SFMX_REQUIRE(c, c && x && y && out && n > 0);
+  const size_t nb = (size_t)n * 8;
+  SFMX_HIP(c, c->d[0].ensure(nb));
+  SFMX_HIP(c, c->d[1].ensure(nb));
+  SFMX_HIP(c, c->d[2].ensure(nb));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, x, nb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, y, nb, hipMemcpyHostToDevice, c->stream));
+  k_debug_hypot<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[2].as<double>());
+  SFMX_HIP(c, hipGetLastError());
+  SFMX_HIP(c, hipMemcpyAsync(out, c->d[2].p, nb, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  return SFMX_OK;
+}
+
+int sfmx_debug_divsqrt(sfmx_ctx* c, const double* x, const double* y, int n, double* dv, double* sq) {
+  SFMX_REQUIRE(c, c && x && y && dv && sq && n > 0);
+  const size_t nb = (size_t)n * 8;
+  for (int i = 0; i < 4; i++) SFMX_HIP(c, c->d[i].ensure(nb));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, x, nb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, y, nb, hipMemcpyHostToDevice, c->stream));
+  k_debug_divsqrt<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n,
+                                                        c->d[2].as<double>(), c->d[3].as<double>());
+  SFMX_HIP(c, hipGetLastError());
+  SFMX_HIP(c, hipMemcpyAsync(dv, c->d[2].p, nb, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(sq, c->d[3].p, nb, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  return SFMX_OK;
+}
+
+}  // extern "C"

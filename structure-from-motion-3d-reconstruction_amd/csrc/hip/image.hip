@@ -1,0 +1,295 @@
+// image.hip — pyramid build (T:200-232) and Shi-Tomasi score map (T:242-272) for gfx950.
+//
+// Both are HBM-streaming kernels: every pixel is read once from HBM (neighbours come from L2/L1)
+// and each output is written once.  Algorithmic bytes:
+//   downsample level l:  read w_l*h_l, write w_l*h_l/4
+//   score map:           read w*h (u8), write 8*w*h (f64)
+#include "sfmx_internal.h"
+
+// ------------------------------------------------------------------------------------------ pyramid
+// One thread per output pixel; 2x2 box, integer sum / 4 (truncation), +1 neighbours clamped.
+__global__ void k_downsample2(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dw || y >= dh) return;
+  const int sx = 2 * x, sy = 2 * y;
+  const int sx1 = min(sx + 1, sw - 1), sy1 = min(sy + 1, sh - 1);
+  const int sum = (int)src[(size_t)sy * sw + sx] + (int)src[(size_t)sy * sw + sx1] + (int)src[(size_t)sy1 * sw + sx] +
+                  (int)src[(size_t)sy1 * sw + sx1];
+  dst[(size_t)y * dw + x] = (uint8_t)(sum / 4);
+}
+
+static int build_levels(sfmx_ctx* c, sfmx_pyramid* p) {
+  for (int l = 1; l < p->levels; l++) {
+    if (p->lw[l] <= 0 || p->lh[l] <= 0) continue;
+    dim3 b(64, 4), g((p->lw[l] + 63) / 64, (p->lh[l] + 3) / 4);
+    k_downsample2<<<g, b, 0, c->stream>>>(p->base + p->off[l - 1], p->lw[l - 1], p->lh[l - 1], p->base + p->off[l], p->lw[l], p->lh[l]);
+    SFMX_HIP(c, hipGetLastError());
+  }
+  return SFMX_OK;
+}
+
+extern "C" {
+
+int sfmx_pyramid_create(sfmx_ctx* c, int w, int h, int levels, sfmx_pyramid** out) {
+  SFMX_REQUIRE(c, c && out && w > 0 && h > 0 && levels >= 1 && levels <= SFMX_MAX_LEVELS);
+  sfmx_pyramid* p = new sfmx_pyramid;
+  p->w = w;
+  p->h = h;
+  p->levels = levels;
+  size_t off = 0;
+  int lw = w, lh = h;
+  for (int l = 0; l < levels; l++) {
+    p->lw[l] = lw;
+    p->lh[l] = lh;
+    p->off[l] = off;
+    off += (((size_t)lw * lh) + 255) & ~(size_t)255;
+    lw /= 2;
+    lh /= 2;
+  }
+  p->bytes = off + 256;
+  hipError_t e = hipMalloc((void**)&p->base, p->bytes);
+  if (e != hipSuccess) {
+    delete p;
+    return sfmx_fail(c, SFMX_ERR_HIP, "hipMalloc(pyramid)", e);
+  }
+  *out = p;
+  return SFMX_OK;
+}
+
+void sfmx_pyramid_destroy(sfmx_ctx* c, sfmx_pyramid* p) {
+  if (!p) return;
+  if (c) (void)hipStreamSynchronize(c->stream);
+  if (p->base) (void)hipFree(p->base);
+  delete p;
+}
+
+int sfmx_pyramid_upload(sfmx_ctx* c, sfmx_pyramid* p, const uint8_t* host_pixels) {
+  SFMX_REQUIRE(c, c && p && host_pixels);
+  SFMX_HIP(c, hipMemcpyAsync(p->base, host_pixels, (size_t)p->w * p->h, hipMemcpyHostToDevice, c->stream));
+  return build_levels(c, p);
+}
+
+int sfmx_pyramid_set_device(sfmx_ctx* c, sfmx_pyramid* p, const void* device_pixels) {
+  SFMX_REQUIRE(c, c && p && device_pixels);
+  SFMX_HIP(c, hipMemcpyAsync(p->base, device_pixels, (size_t)p->w * p->h, hipMemcpyDeviceToDevice, c->stream));
+  return build_levels(c, p);
+}
+
+int sfmx_pyramid_download_level(sfmx_ctx* c, const sfmx_pyramid* p, int level, uint8_t* host_out) {
+  SFMX_REQUIRE(c, c && p && host_out && level >= 0 && level < p->levels);
+  const size_t nb = (size_t)p->lw[level] * p->lh[level];
+  if (nb == 0) return SFMX_OK;
+  SFMX_HIP(c, hipMemcpyAsync(host_out, p->base + p->off[level], nb, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  return SFMX_OK;
+}
+
+int sfmx_pyramid_level_size(const sfmx_pyramid* p, int level, int* w, int* h) {
+  if (!p || level < 0 || level >= p->levels) return SFMX_ERR_INVALID;
+  if (w) *w = p->lw[level];
+  if (h) *h = p->lh[level];
+  return SFMX_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------ Shi-Tomasi
+// Tile = 64 x 8 output pixels per 256-thread... (512-thread) block.  The u8 tile plus a 3-pixel halo
+// (2 for the 5x5 box + 1 for the central difference, indices clamped exactly like T:242-249) is
+// staged in LDS once; gradients are exact halves of small integers, so gx*gx etc. and the 25-term
+// sums are exact in FP64 and the only rounding steps are tr*tr-4*det and the (correctly rounded)
+// sqrt — evaluated in the reference's order.
+#define ST_TX 64
+#define ST_TY 8
+#define ST_HALO 3
+#define ST_LW (ST_TX + 2 * ST_HALO)
+#define ST_LH (ST_TY + 2 * ST_HALO)
+
+__global__ __launch_bounds__(ST_TX* ST_TY) void k_shi_score(const uint8_t* __restrict__ img, int w, int h,
+                                                            double* __restrict__ score, unsigned long long* __restrict__ max_bits) {
+  __shared__ uint8_t tile[ST_LH][ST_LW + 2];
+  __shared__ unsigned long long wave_max[(ST_TX * ST_TY) / 64];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int x0 = blockIdx.x * ST_TX, y0 = blockIdx.y * ST_TY;
+  const int tid = ty * ST_TX + tx;
+  // LDS holds the image value at CLAMPED coordinates, so tile[yy][xx] == im.at(clamp) for every
+  // index the gradient lambdas can form.
+  for (int i = tid; i < ST_LH * ST_LW; i += ST_TX * ST_TY) {
+    const int ly = i / ST_LW, lx = i % ST_LW;
+    const int gx = min(max(x0 + lx - ST_HALO, 0), w - 1);
+    const int gy = min(max(y0 + ly - ST_HALO, 0), h - 1);
+    tile[ly][lx] = img[(size_t)gy * w + gx];
+  }
+  __syncthreads();
+  const int x = x0 + tx, y = y0 + ty;
+  double s = 0.0;
+  const bool inside = (x < w && y < h);
+  if (inside && x >= 2 && x < w - 2 && y >= 2 && y < h - 2) {
+    double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+    for (int dy = -2; dy <= 2; ++dy) {
+#pragma unroll
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int ly = ty + ST_HALO + dy, lx = tx + ST_HALO + dx;
+        // clamping of xm/xp/ym/yp (T:243,247) is already folded into the tile contents, EXCEPT that
+        // the lambdas clamp the neighbour index, not the centre: centre (xx,yy) is always in-image here.
+        const double gx = 0.5 * ((double)tile[ly][lx + 1] - (double)tile[ly][lx - 1]);
+        const double gy = 0.5 * ((double)tile[ly + 1][lx] - (double)tile[ly - 1][lx]);
+        sxx += gx * gx;
+        sxy += gx * gy;
+        syy += gy * gy;
+      }
+    }
+    const double tr = sxx + syy;
+    const double det = sxx * syy - sxy * sxy;
+    const double d0 = tr * tr - 4.0 * det;
+    const double disc = (0.0 < d0) ? d0 : 0.0;  // std::max(0.0, d0)
+    s = 0.5 * (tr - sqrt(disc));
+  }
+  if (inside) score[(size_t)y * w + x] = s;
+  // block max of the (non-negative) scores via their bit patterns
+  unsigned long long b = inside ? (unsigned long long)__double_as_longlong(s) : 0ull;
+  if (s < 0.0 || s != s) b = 0ull;  // cannot happen for exact inputs; keeps the reduction monotone
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_down(b, o, 64);
+    b = t > b ? t : b;
+  }
+  if ((tid & 63) == 0) wave_max[tid >> 6] = b;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long m = wave_max[0];
+    for (int i = 1; i < (ST_TX * ST_TY) / 64; i++) m = wave_max[i] > m ? wave_max[i] : m;
+    atomicMax(max_bits, m);
+  }
+}
+
+// Ordered compaction of candidates (score >= thr) in row-major order: one block per image row
+// counts, a single-block scan turns counts into offsets, a second pass writes.  Row-major order is
+// part of the contract (it is the std::sort input order at T:286).
+__global__ void k_row_count(const double* __restrict__ score, int w, int h, const unsigned long long* __restrict__ max_bits,
+                            double quality, int* __restrict__ row_count) {
+  const int y = blockIdx.x;
+  const double thr = __longlong_as_double((long long)*max_bits) * quality;
+  int c = 0;
+  for (int x = threadIdx.x; x < w; x += blockDim.x) c += (score[(size_t)y * w + x] >= thr) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  __shared__ int part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += part[i];
+    row_count[y] = t;
+  }
+}
+__global__ void k_row_scan(int* __restrict__ row_count, int h, int* __restrict__ total) {
+  // exclusive scan by one wave-strided thread block (h <= a few thousand rows)
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < h; base += 64) {
+    const int i = base + (int)threadIdx.x;
+    int v = (i < h) ? row_count[i] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if ((int)threadIdx.x >= o) incl += t;
+    }
+    const int c = carry;
+    if (i < h) row_count[i] = c + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 63) carry = c + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+__global__ void k_row_write(const double* __restrict__ score, int w, int h, const unsigned long long* __restrict__ max_bits,
+                            double quality, const int* __restrict__ row_off, int cap, uint32_t* __restrict__ cand_xy,
+                            double* __restrict__ cand_s) {
+  // one wave per row keeps the in-row order with a ballot prefix
+  const int y = blockIdx.x;
+  const double thr = __longlong_as_double((long long)*max_bits) * quality;
+  int off = row_off[y];
+  for (int base = 0; base < w; base += 64) {
+    const int x = base + (int)threadIdx.x;
+    const double s = (x < w) ? score[(size_t)y * w + x] : -1.0;
+    const bool hit = (x < w) && (s >= thr);
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int pos = off + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      if (pos < cap) {
+        cand_xy[pos] = (uint32_t)x | ((uint32_t)y << 16);
+        cand_s[pos] = s;
+      }
+    }
+    off += __popcll(m);
+  }
+}
+
+static int launch_score(sfmx_ctx* c, const sfmx_pyramid* p, double* d_score, unsigned long long* d_max) {
+  SFMX_HIP(c, hipMemsetAsync(d_max, 0, 8, c->stream));
+  dim3 b(ST_TX, ST_TY), g((p->w + ST_TX - 1) / ST_TX, (p->h + ST_TY - 1) / ST_TY);
+  KernelTimer t(c);
+  t.start();
+  k_shi_score<<<g, b, 0, c->stream>>>(p->base + p->off[0], p->w, p->h, d_score, d_max);
+  t.stop();
+  SFMX_HIP(c, hipGetLastError());
+  return SFMX_OK;
+}
+
+extern "C" {
+
+int sfmx_shi_tomasi_score(sfmx_ctx* c, const sfmx_pyramid* p, double* score_out, double* max_out) {
+  SFMX_REQUIRE(c, c && p && (score_out || max_out));
+  const size_t n = (size_t)p->w * p->h;
+  SFMX_HIP(c, c->d[0].ensure(n * 8));
+  SFMX_HIP(c, c->d[1].ensure(64));
+  int rc = launch_score(c, p, c->d[0].as<double>(), c->d[1].as<unsigned long long>());
+  if (rc) return rc;
+  double mx = 0;
+  if (score_out) SFMX_HIP(c, hipMemcpyAsync(score_out, c->d[0].p, n * 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&mx, c->d[1].p, 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  KernelTimer(c).collect();
+  if (max_out) *max_out = mx;
+  return SFMX_OK;
+}
+
+int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int cap, uint32_t* cand_xy,
+                               double* cand_score, int* n_out, double* max_out) {
+  SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 65536 && p->h < 65536);
+  const size_t n = (size_t)p->w * p->h;
+  SFMX_HIP(c, c->d[0].ensure(n * 8));
+  SFMX_HIP(c, c->d[1].ensure(64));
+  SFMX_HIP(c, c->d[2].ensure((size_t)(p->h + 1) * 4 + 64));
+  SFMX_HIP(c, c->d[3].ensure((size_t)cap * 4));
+  SFMX_HIP(c, c->d[4].ensure((size_t)cap * 8));
+  unsigned long long* d_max = c->d[1].as<unsigned long long>();
+  int* d_rows = c->d[2].as<int>();
+  int* d_total = d_rows + p->h;
+  int rc = launch_score(c, p, c->d[0].as<double>(), d_max);
+  if (rc) return rc;
+  k_row_count<<<p->h, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_rows);
+  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_total);
+  k_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_rows, cap, c->d[3].as<uint32_t>(),
+                                          c->d[4].as<double>());
+  SFMX_HIP(c, hipGetLastError());
+  int total = 0;
+  double mx = 0;
+  SFMX_HIP(c, hipMemcpyAsync(&total, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  KernelTimer(c).collect();
+  const int m = total < cap ? total : cap;
+  if (m > 0) {
+    SFMX_HIP(c, hipMemcpyAsync(cand_xy, c->d[3].p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipMemcpyAsync(cand_score, c->d[4].p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  *n_out = total;
+  if (max_out) *max_out = mx;
+  return SFMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+// klt.hip — pyramidal LK forward + backward tracking with the forward-backward test, for gfx950.
+//
+// Replaces KLTTracker::track_one / lk_step and the FB test of KLTTracker::step
+// (reference cpp/src/templering_sfm.cpp T:356-362, 402-460).
+//
+// Mapping: ONE 64-lane wavefront per track (block = 1 wave, so __syncthreads() is a wave-local
+// ordering point and every wave may run its own trip count: the early exit at T:416 is per track).
+//
+//  * LDS staging: a 32x32 window of both pyramid images around the current estimate is copied to
+//    LDS as f32 (u8 -> f32 is exact) once per level and re-staged only when the (2r+5)-wide
+//    footprint of an lk_step leaves it.  Row stride 33 keeps the 11x11 access pattern off the
+//    same bank.
+//  * per-pixel phase (parallel): lane l owns window pixels l, l+64, ...; each pixel evaluates the six
+//    bilinear samples of T:438-441 with the reference's exact expressions (floor, x - x0,
+//    v00*(1-dx)+v10*dx, rows first) and the five products Ix*Ix, Ix*Iy, Iy*Iy, Ix*err, Iy*err.
+//  * ordered reduction (serial by contract): FP64 addition is not associative and parity is
+//    bit-exact, so the (2r+1)^2 products of each accumulator are added in the reference's
+//    (dy outer, dx inner) sequence: lanes 0..4 each walk one accumulator's products in LDS.
+//  * 2x2 solve, hypot-based stop test (glibc-compatible hypot, sfmx_math.h), level loop, then the
+//    backward pass from the forward result and keep = !(hypot(back - p0) >= fb_thresh).
+//
+// No FMA contraction anywhere (-ffp-contract=off); FP64 division and sqrt are the correctly
+// rounded forms.
+#include "sfmx_internal.h"
+
+#define KLT_P 32          // staged window is KLT_P x KLT_P pixels
+#define KLT_PS 33         // LDS row stride (floats)
+#define KLT_MAX_R 7
+#define KLT_MAX_NPIX ((2 * KLT_MAX_R + 1) * (2 * KLT_MAX_R + 1))
+
+struct Tap {   // one coordinate of a bilinear sample: integer base, fraction, in-image flag
+  int i0;
+  double f;
+  bool ok;
+};
+__device__ __forceinline__ Tap make_tap(double v, int extent) {
+  Tap t;
+  t.i0 = sfmx::floor_to_int_x86(v);
+  t.f = v - (double)t.i0;
+  t.ok = (t.i0 >= 0) && (t.i0 < extent - 1);  // x0 >= 0 && x0+1 < w   (T:188)
+  return t;
+}
+// T:183-198 on the staged window (ox,oy = window origin in image coordinates)
+__device__ __forceinline__ double sample_lds(const float* __restrict__ win, int ox, int oy, const Tap& cx, const Tap& cy) {
+  if (!(cx.ok && cy.ok)) return 0.0;
+  int lx = cx.i0 - ox, ly = cy.i0 - oy;
+  lx = min(max(lx, 0), KLT_P - 2);  // defensive: never leaves the window (ensure_window guarantees it)
+  ly = min(max(ly, 0), KLT_P - 2);
+  const float* p = win + ly * KLT_PS + lx;
+  const double v00 = (double)p[0], v10 = (double)p[1], v01 = (double)p[KLT_PS], v11 = (double)p[KLT_PS + 1];
+  const double v0 = v00 * (1 - cx.f) + v10 * cx.f;
+  const double v1 = v01 * (1 - cx.f) + v11 * cx.f;
+  return v0 * (1 - cy.f) + v1 * cy.f;
+}
+
+__device__ __forceinline__ void stage_window(const uint8_t* __restrict__ img, int w, int h, int ox, int oy, float* __restrict__ win, int lane) {
+  for (int i = lane; i < KLT_P * KLT_P; i += 64) {
+    const int py = i / KLT_P, px = i % KLT_P;
+    const int gx = ox + px, gy = oy + py;
+    float v = 0.f;
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = (float)img[(size_t)gy * w + gx];
+    win[py * KLT_PS + px] = v;
+  }
+}
+
+// integer part of a coordinate for window bookkeeping only (saturating; NaN -> far away)
+__device__ __forceinline__ int book_floor(double v) {
+  if (!(v > -1.0e9 && v < 1.0e9)) return (int)0x40000000;
+  return (int)floor(v);
+}
+
+__global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels, int r,
+                                                  int iters, double fb_thresh, double* __restrict__ xy_fwd,
+                                                  double* __restrict__ xy_back, uint8_t* __restrict__ keep,
+                                                  unsigned long long* __restrict__ step_counter) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* win0 = reinterpret_cast<float*>(smem);                 // template image window (I0 of lk_step)
+  float* win1 = win0 + KLT_P * KLT_PS;                          // current image window  (I1 of lk_step)
+  double* prod = reinterpret_cast<double*>(win1 + KLT_P * KLT_PS);      // [5][npix_pad], 16-B aligned
+  const int lane = threadIdx.x;
+  const int track = blockIdx.x;
+  if (track >= n) return;
+  const int side = 2 * r + 1, npix = side * side;
+  const int npad = (npix + 1) & ~1;
+
+  const double p0x = xy_in[2 * track], p0y = xy_in[2 * track + 1];
+  double px = p0x, py = p0y;
+  unsigned int steps = 0;
+
+  for (int dir = 0; dir < 2; ++dir) {
+    for (int l = levels - 1; l >= 0; --l) {
+      const uint8_t* img0 = dir == 0 ? A.px[l] : B.px[l];
+      const uint8_t* img1 = dir == 0 ? B.px[l] : A.px[l];
+      const int w = A.w[l], h = A.h[l];
+      const double scale = 1.0 / (double)(1 << l);
+      const double plx = px * scale, ply = py * scale;
+      double dlx = 0.0, dly = 0.0;
+      int ox = (int)0x7fffff00, oy = (int)0x7fffff00;  // no window staged yet
+      for (int it = 0; it < iters; ++it) {
+        const double x = plx + dlx, y = ply + dly;
+        // ---- make sure the staged window covers the footprint [b-r-2, b+r+3] of this step
+        const int bx = book_floor(x), by = book_floor(y);
+        const bool touches = (bx + r + 3 >= 0) && (bx - r - 2 < w) && (by + r + 3 >= 0) && (by - r - 2 < h);
+        if (touches) {
+          const bool covered = (bx - r - 2 >= ox) && (bx + r + 3 < ox + KLT_P) && (by - r - 2 >= oy) && (by + r + 3 < oy + KLT_P);
+          if (!covered) {
+            ox = bx - (KLT_P / 2 - 1);
+            oy = by - (KLT_P / 2 - 1);
+            __syncthreads();
+            stage_window(img0, w, h, ox, oy, win0, lane);
+            stage_window(img1, w, h, ox, oy, win1, lane);
+            __syncthreads();
+          }
+        }
+        // ---- per-pixel products (T:433-449)
+        for (int pix = lane; pix < npix; pix += 64) {
+          const int dyi = pix / side - r, dxi = pix % side - r;
+          const double xx = x + (double)dxi, yy = y + (double)dyi;
+          const Tap cx0 = make_tap(xx, w), cxp = make_tap(xx + 1, w), cxm = make_tap(xx - 1, w);
+          const Tap cy0 = make_tap(yy, h), cyp = make_tap(yy + 1, h), cym = make_tap(yy - 1, h);
+          const double Ix = 0.5 * (sample_lds(win1, ox, oy, cxp, cy0) - sample_lds(win1, ox, oy, cxm, cy0));
+          const double Iy = 0.5 * (sample_lds(win1, ox, oy, cx0, cyp) - sample_lds(win1, ox, oy, cx0, cym));
+          const double Iref = sample_lds(win0, ox, oy, cx0, cy0);
+          const double Icur = sample_lds(win1, ox, oy, cx0, cy0);
+          const double err = Iref - Icur;
+          prod[0 * npad + pix] = Ix * Ix;
+          prod[1 * npad + pix] = Ix * Iy;
+          prod[2 * npad + pix] = Iy * Iy;
+          prod[3 * npad + pix] = Ix * err;
+          prod[4 * npad + pix] = Iy * err;
+        }
+        __syncthreads();
+        // ---- ordered sums: lane k < 5 adds accumulator k's products in reference order
+        double acc = 0.0;
+        if (lane < 5) {
+          const double* q = prod + lane * npad;
+          int i = 0;
+          for (; i + 1 < npix; i += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(q + i);
+            acc += v.x;
+            acc += v.y;
+          }
+          if (i < npix) acc += q[i];
+        }
+        __syncthreads();  // products consumed; next iteration may overwrite
+        const double A00 = __shfl(acc, 0, 64), A01 = __shfl(acc, 1, 64), A11 = __shfl(acc, 2, 64);
+        const double b0 = __shfl(acc, 3, 64), b1 = __shfl(acc, 4, 64);
+        // ---- 2x2 solve (T:451-459)
+        double sx = 0.0, sy = 0.0;
+        const double detA = A00 * A11 - A01 * A01;
+        if (!(fabs(detA) < 1e-9)) {
+          const double inv00 = A11 / detA, inv01 = -A01 / detA, inv11 = A00 / detA;
+          sx = inv00 * b0 + inv01 * b1;
+          sy = inv01 * b0 + inv11 * b1;
+        }
+        ++steps;
+        dlx += sx;
+        dly += sy;
+        if (sfmx::hypot_glibc(sx, sy) < 1e-3) break;
+      }
+      px = (plx + dlx) * (double)(1 << l);
+      py = (ply + dly) * (double)(1 << l);
+    }
+    if (dir == 0 && lane == 0) {
+      xy_fwd[2 * track] = px;
+      xy_fwd[2 * track + 1] = py;
+    }
+  }
+  if (lane == 0) {
+    if (xy_back) {
+      xy_back[2 * track] = px;
+      xy_back[2 * track + 1] = py;
+    }
+    const double fb = sfmx::hypot_glibc(px - p0x, py - p0y);
+    keep[track] = (fb >= fb_thresh) ? 0 : 1;  // T:362: `if (fb >= thresh) continue;`
+    if (step_counter) atomicAdd(step_counter, (unsigned long long)steps);
+  }
+}
+
+extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_pyramid* pb, const double* xy_in, int n,
+                              const sfmx_klt_cfg* cfg, double* xy_fwd, double* xy_back, uint8_t* keep, uint64_t* n_steps_out) {
+  SFMX_REQUIRE(c, c && pa && pb && cfg && xy_fwd && keep && n >= 0);
+  SFMX_REQUIRE(c, pa->w == pb->w && pa->h == pb->h && pa->levels == pb->levels);
+  SFMX_REQUIRE(c, cfg->levels >= 1 && cfg->levels <= pa->levels && cfg->win_radius >= 1 && cfg->win_radius <= KLT_MAX_R && cfg->iters >= 0);
+  if (n_steps_out) *n_steps_out = 0;
+  if (n == 0) return SFMX_OK;
+  SFMX_REQUIRE(c, xy_in != nullptr);
+  const size_t nb = (size_t)n * 16;
+  SFMX_HIP(c, c->d[0].ensure(nb));       // xy_in
+  SFMX_HIP(c, c->d[1].ensure(nb));       // fwd
+  SFMX_HIP(c, c->d[2].ensure(nb));       // back
+  SFMX_HIP(c, c->d[3].ensure((size_t)n + 64));  // keep
+  SFMX_HIP(c, c->d[4].ensure(64));       // step counter
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xy_in, nb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemsetAsync(c->d[4].p, 0, 8, c->stream));
+  const int r = cfg->win_radius, npix = (2 * r + 1) * (2 * r + 1), npad = (npix + 1) & ~1;
+  const size_t shmem = (size_t)(2 * KLT_P * KLT_PS) * sizeof(float) + (size_t)5 * npad * sizeof(double);
+  KernelTimer t(c);
+  t.start();
+  k_klt_track<<<n, 64, shmem, c->stream>>>(make_desc(pa), make_desc(pb), c->d[0].as<double>(), n, cfg->levels, r, cfg->iters,
+                                           cfg->fb_thresh, c->d[1].as<double>(), c->d[2].as<double>(), c->d[3].as<uint8_t>(),
+                                           c->d[4].as<unsigned long long>());
+  t.stop();
+  SFMX_HIP(c, hipGetLastError());
+  SFMX_HIP(c, hipMemcpyAsync(xy_fwd, c->d[1].p, nb, hipMemcpyDeviceToHost, c->stream));
+  if (xy_back) SFMX_HIP(c, hipMemcpyAsync(xy_back, c->d[2].p, nb, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(keep, c->d[3].p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long steps = 0;
+  if (n_steps_out) SFMX_HIP(c, hipMemcpyAsync(&steps, c->d[4].p, 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  t.collect();
+  if (n_steps_out) *n_steps_out = steps;
+  return SFMX_OK;
+}

@@ -1,0 +1,411 @@
+// ransac.hip — 8-point hypothesis generation and Sampson-error scoring for gfx950.
+//
+// Replaces the hypothesis loop of find_E_ransac (reference cpp/src/templering_sfm.cpp T:664-677):
+// eight_point_E (T:609-627: 8x9 design matrix, AtA, 9x9 Jacobi, rank-2 projection through svd3)
+// and the per-point sampson_err test (T:629-638, T:669-672).
+//
+// Parity contract: inlier COUNTS and MASKS are integer results and must equal
+// the reference's.  The Sampson kernels evaluate T:629-638 operation for operation (no FMA), so
+// for a given E the mask is bit-exact.  Hypothesis generation contains the reference's only
+// libm-dependent step on this path (phi = 0.5*atan2(2apq, aqq-app); cos/sin, linalg.hpp:156-157),
+// which no device library reproduces bit-for-bit; the device therefore forms the same Jacobi
+// rotation algebraically (half-angle identities, <= 2 ulp from the libm values) and its E's are
+// used ONLY to rank hypotheses.  The host re-derives the winner's E with the platform libm and the
+// final mask is recomputed from that E by k_sampson_mask, so everything that leaves the library is
+// bit-identical to the reference as long as the ranking agrees (tests/ verifies on all fixtures).
+//
+// k_hypotheses: 16 lanes per hypothesis, 4 hypotheses per wavefront, matrices in LDS; the pivot
+//   search and the row / column / eigenvector rotations are spread over the lanes and reduced with
+//   16-lane shuffles (first-maximum tie-break = the reference's row-major strict '>' scan).
+// k_score: 256 threads x 8 hypotheses per block; each point (32 B, coalesced from L2) is loaded once
+//   per block and tested against the block's 8 essential matrices, which sit in SGPRs (uniform loads).
+#include "sfmx_internal.h"
+
+#define HG 16  // lanes per hypothesis
+#define HPW 4  // hypotheses per wave
+
+struct Rot { double c, s; };
+// Jacobi rotation of linalg.hpp:153-157 without libm: phi = atan2(y, x)/2 in (-pi/2, pi/2].
+__device__ __forceinline__ Rot half_angle(double y, double x) {
+  Rot r;
+  const double h = sqrt(y * y + x * x);
+  if (!(h > 0.0)) {
+    r.c = 1.0;
+    r.s = 0.0;
+    return r;
+  }
+  const double c2 = x / h, s2 = y / h;
+  if (x >= 0.0) {
+    r.c = sqrt(0.5 * (1.0 + c2));
+    r.s = s2 / (2.0 * r.c);
+  } else {
+    const double sa = sqrt(0.5 * (1.0 - c2));
+    r.s = (y < 0.0) ? -sa : sa;
+    r.c = fabs(s2) / (2.0 * sa);
+  }
+  return r;
+}
+
+__device__ __forceinline__ double shfl_xor16(double v, int o) { return __shfl_xor(v, o, HG); }
+
+// serial 3x3 Jacobi (linalg.hpp:133-201, N=3) on LDS-resident A3/V3, executed by one lane
+__device__ void jacobi3_lds(double* A, double* V, int sweeps) {
+  for (int i = 0; i < 9; i++) V[i] = 0.0;
+  V[0] = V[4] = V[8] = 1.0;
+  for (int it = 0; it < sweeps; ++it) {
+    int p = 0, q = 1;
+    double big = 0.0;
+    const double a01 = fabs(A[1]), a02 = fabs(A[2]), a12 = fabs(A[5]);
+    if (a01 > big) { big = a01; p = 0; q = 1; }
+    if (a02 > big) { big = a02; p = 0; q = 2; }
+    if (a12 > big) { big = a12; p = 1; q = 2; }
+    if (big < 1e-12) break;
+    const Rot r = half_angle(2.0 * A[p * 3 + q], A[q * 3 + q] - A[p * 3 + p]);
+    const double c = r.c, s = r.s;
+    for (int k = 0; k < 3; k++) {
+      const double ap = A[p * 3 + k], aq = A[q * 3 + k];
+      A[p * 3 + k] = c * ap - s * aq;
+      A[q * 3 + k] = s * ap + c * aq;
+    }
+    for (int k = 0; k < 3; k++) {
+      const double ap = A[k * 3 + p], aq = A[k * 3 + q];
+      A[k * 3 + p] = c * ap - s * aq;
+      A[k * 3 + q] = s * ap + c * aq;
+    }
+    A[p * 3 + q] = 0.0;
+    A[q * 3 + p] = 0.0;
+    for (int k = 0; k < 3; k++) {
+      const double vp = V[k * 3 + p], vq = V[k * 3 + q];
+      V[k * 3 + p] = c * vp - s * vq;
+      V[k * 3 + q] = s * vp + c * vq;
+    }
+  }
+}
+
+__device__ __forceinline__ void unit3(double& x, double& y, double& z) {
+  const double n = sqrt(x * x + y * y + z * z);
+  if (!isfinite(n) || n < 1e-12) { x = y = z = 0.0; return; }
+  x = x / n; y = y / n; z = z / n;
+}
+
+// T:537-607: E -> U diag(s0,s1,0) V^T, executed by one lane; E9 in/out in LDS, scratch: A3,V3 (LDS)
+__device__ void rank2_project(double* E, double* A3, double* V3) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; k++) acc += E[3 * k + r] * E[3 * k + c];
+      A3[3 * r + c] = acc;
+    }
+  jacobi3_lds(A3, V3, 80);
+  double w[3] = {A3[0], A3[4], A3[8]};
+  // eigenvalues ascending (insertion sort as libstdc++ does for N<=16), then singular values descending
+  int pe[3] = {0, 1, 2};
+  for (int i = 1; i < 3; i++) {
+    const int val = pe[i];
+    if (w[val] < w[pe[0]]) { for (int k = i; k > 0; k--) pe[k] = pe[k - 1]; pe[0] = val; }
+    else { int k = i; while (w[val] < w[pe[k - 1]]) { pe[k] = pe[k - 1]; k--; } pe[k] = val; }
+  }
+  double sv[3];
+  for (int i = 0; i < 3; i++) { const double wi = w[pe[i]]; sv[i] = sqrt((0.0 < wi) ? wi : 0.0); }
+  int od[3] = {0, 1, 2};
+  for (int i = 1; i < 3; i++) {
+    const int val = od[i];
+    if (sv[val] > sv[od[0]]) { for (int k = i; k > 0; k--) od[k] = od[k - 1]; od[0] = val; }
+    else { int k = i; while (sv[val] > sv[od[k - 1]]) { od[k] = od[k - 1]; k--; } od[k] = val; }
+  }
+  double Vd[9], sd[3];
+  for (int c = 0; c < 3; c++) {
+    sd[c] = sv[od[c]];
+    const int src = pe[od[c]];
+    for (int r = 0; r < 3; r++) Vd[3 * r + c] = V3[3 * r + src];
+  }
+  double U[9];
+  for (int c = 0; c < 3; c++) {
+    const double vx = Vd[c], vy = Vd[3 + c], vz = Vd[6 + c];
+    double ux = E[0] * vx + E[1] * vy + E[2] * vz;
+    double uy = E[3] * vx + E[4] * vy + E[5] * vz;
+    double uz = E[6] * vx + E[7] * vy + E[8] * vz;
+    if (sd[c] > 1e-12) { ux = ux / sd[c]; uy = uy / sd[c]; uz = uz / sd[c]; }
+    else unit3(ux, uy, uz);
+    U[c] = ux; U[3 + c] = uy; U[6 + c] = uz;
+  }
+  double u0x = U[0], u0y = U[3], u0z = U[6], u1x = U[1], u1y = U[4], u1z = U[7];
+  unit3(u0x, u0y, u0z);
+  const double d01 = u0x * u1x + u0y * u1y + u0z * u1z;
+  u1x = u1x - d01 * u0x; u1y = u1y - d01 * u0y; u1z = u1z - d01 * u0z;
+  unit3(u1x, u1y, u1z);
+  double u2x = u0y * u1z - u0z * u1y, u2y = u0z * u1x - u0x * u1z, u2z = u0x * u1y - u0y * u1x;
+  unit3(u2x, u2y, u2z);
+  U[0] = u0x; U[3] = u0y; U[6] = u0z; U[1] = u1x; U[4] = u1y; U[7] = u1z; U[2] = u2x; U[5] = u2y; U[8] = u2z;
+  // US = U * diag(s0,s1,0) with the reference's full 3-term sums, then (US) * V^T
+  const double S[9] = {sd[0], 0, 0, 0, sd[1], 0, 0, 0, 0.0};
+  double US[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; k++) acc += U[3 * r + k] * S[3 * k + c];
+      US[3 * r + c] = acc;
+    }
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double acc = 0.0;
+      for (int k = 0; k < 3; k++) acc += US[3 * r + k] * Vd[3 * c + k];  // Vt(k,c) = V(c,k)
+      E[3 * r + c] = acc;
+    }
+}
+
+struct HypLds {
+  double D[72];   // 8x9 design matrix
+  double A[81];   // AtA, rotated in place
+  double V[81];   // eigenvectors (columns)
+  double E[9];
+  double A3[9], V3[9];
+};
+
+__global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi, const double* __restrict__ xj, int n,
+                                                   const int32_t* __restrict__ idx8, int H, int sweeps, double* __restrict__ E_out) {
+  __shared__ HypLds lds[HPW];
+  const int lane = threadIdx.x, g = lane / HG, t = lane % HG;
+  const int hyp = blockIdx.x * HPW + g;
+  const bool live = hyp < H;
+  HypLds& L = lds[g];
+  // ---- design matrix rows (T:612-618)
+  if (live && t < 8) {
+    int i = idx8[(size_t)hyp * 8 + t];
+    i = min(max(i, 0), n - 1);
+    const double x = xi[2 * i], y = xi[2 * i + 1], xp = xj[2 * i], yp = xj[2 * i + 1];
+    double* row = L.D + 9 * t;
+    row[0] = xp * x; row[1] = xp * y; row[2] = xp;
+    row[3] = yp * x; row[4] = yp * y; row[5] = yp;
+    row[6] = x; row[7] = y; row[8] = 1.0;
+  }
+  __syncthreads();
+  // ---- AtA upper triangle, mirrored (T:503-517): 45 entries over 16 lanes
+  if (live) {
+    for (int e = t; e < 45; e += HG) {
+      int i = 0, rem = e;
+      while (rem >= 9 - i) { rem -= 9 - i; i++; }
+      const int j = i + rem;
+      double acc = 0.0;
+      for (int r = 0; r < 8; r++) acc += L.D[r * 9 + i] * L.D[r * 9 + j];
+      L.A[i * 9 + j] = acc;
+      L.A[j * 9 + i] = acc;
+    }
+    for (int e = t; e < 81; e += HG) L.V[e] = (e / 9 == e % 9) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // ---- 9x9 Jacobi (linalg.hpp:141-186)
+  bool active = live;
+  for (int it = 0; it < sweeps; ++it) {
+    // pivot: largest |A[i][j]|, i<j, first in row-major order (36 candidates over 16 lanes)
+    double bv = -1.0;
+    int be = 0;
+    if (active) {
+      for (int e = t; e < 36; e += HG) {
+        int i = 0, rem = e;
+        while (rem >= 8 - i) { rem -= 8 - i; i++; }
+        const int j = i + 1 + rem;
+        const double v = fabs(L.A[i * 9 + j]);
+        if (v > bv) { bv = v; be = e; }  // NaN never wins, as in the reference's `v > maxv`
+      }
+    }
+    for (int o = HG / 2; o > 0; o >>= 1) {
+      const double ov = shfl_xor16(bv, o);
+      const int oe = __shfl_xor(be, o, HG);
+      if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
+    }
+    if (active && !(bv > 0.0 && !(bv < 1e-12))) active = false;  // maxv < 1e-12 -> break (incl. all-zero / all-NaN)
+    if (!__any(active)) break;
+    int p = 0, rem = be;
+    while (rem >= 8 - p) { rem -= 8 - p; p++; }
+    const int q = p + 1 + rem;
+    Rot r;
+    r.c = 1.0; r.s = 0.0;
+    if (active) r = half_angle(2.0 * L.A[p * 9 + q], L.A[q * 9 + q] - L.A[p * 9 + p]);
+    const double c = r.c, s = r.s;
+    __syncthreads();
+    if (active && t < 9) {  // rows p,q
+      const double ap = L.A[p * 9 + t], aq = L.A[q * 9 + t];
+      L.A[p * 9 + t] = c * ap - s * aq;
+      L.A[q * 9 + t] = s * ap + c * aq;
+    }
+    __syncthreads();
+    if (active && t < 9) {  // columns p,q on the row-updated matrix
+      const double ap = L.A[t * 9 + p], aq = L.A[t * 9 + q];
+      L.A[t * 9 + p] = c * ap - s * aq;
+      L.A[t * 9 + q] = s * ap + c * aq;
+      const double vp = L.V[t * 9 + p], vq = L.V[t * 9 + q];
+      L.V[t * 9 + p] = c * vp - s * vq;
+      L.V[t * 9 + q] = s * vp + c * vq;
+    }
+    __syncthreads();
+    if (active && t == 0) {
+      L.A[p * 9 + q] = 0.0;
+      L.A[q * 9 + p] = 0.0;
+    }
+    __syncthreads();
+  }
+  // ---- smallest eigenvector -> E -> rank 2 (one lane per hypothesis)
+  if (live && t == 0) {
+    // only the FIRST element of the stable ascending eigenvalue sort (linalg.hpp:188-191) is
+    // needed: the first strict minimum of the diagonal
+    int col = 0;
+    double wmin = L.A[0];
+    for (int i = 1; i < 9; i++) {
+      const double wi = L.A[i * 9 + i];
+      if (wi < wmin) { wmin = wi; col = i; }
+    }
+    for (int r = 0; r < 9; r++) L.E[r] = L.V[r * 9 + col];
+    rank2_project(L.E, L.A3, L.V3);
+    for (int r = 0; r < 9; r++) E_out[(size_t)hyp * 9 + r] = L.E[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ scoring
+// T:629-638 for one point and one E (E passed as 9 scalars so that it can live in SGPRs).
+// Products by the homogeneous 1.0 are exact identities and are elided; the additions keep the
+// reference's left-to-right order.
+__device__ __forceinline__ double sampson_eval(double e0, double e1, double e2, double e3, double e4, double e5, double e6,
+                                               double e7, double e8, double x, double y, double xp, double yp) {
+  const double Exx = e0 * x + e1 * y + e2;
+  const double Exy = e3 * x + e4 * y + e5;
+  const double Exz = e6 * x + e7 * y + e8;
+  const double Etx = e0 * xp + e3 * yp + e6;
+  const double Ety = e1 * xp + e4 * yp + e7;
+  const double q = xp * Exx + yp * Exy + Exz;
+  const double den = Exx * Exx + Exy * Exy + Etx * Etx + Ety * Ety + 1e-12;
+  return (q * q) / den;
+}
+
+#define SC_HB 8
+#define SC_THREADS 256
+__global__ __launch_bounds__(SC_THREADS) void k_score(const double* __restrict__ xi, const double* __restrict__ xj, int n,
+                                                      const double* __restrict__ E, int H, double thr, int32_t* __restrict__ counts) {
+  __shared__ int part[SC_THREADS / 64][SC_HB];
+  const int h0 = blockIdx.x * SC_HB;
+  const int tid = threadIdx.x;
+  int cnt[SC_HB];
+#pragma unroll
+  for (int k = 0; k < SC_HB; k++) cnt[k] = 0;
+  const double2* __restrict__ pi = reinterpret_cast<const double2*>(xi);
+  const double2* __restrict__ pj = reinterpret_cast<const double2*>(xj);
+  for (int i = tid; i < n; i += SC_THREADS) {
+    const double2 a = pi[i], b = pj[i];
+#pragma unroll
+    for (int k = 0; k < SC_HB; k++) {
+      const int h = min(h0 + k, H - 1);          // uniform -> scalar loads of E
+      const double* e = E + (size_t)h * 9;
+      const double err = sampson_eval(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], a.x, a.y, b.x, b.y);
+      cnt[k] += (err < thr) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SC_HB; k++) {
+    int v = cnt[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((tid & 63) == 0) part[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < SC_HB && h0 + tid < H) {
+    int v = 0;
+    for (int w = 0; w < SC_THREADS / 64; w++) v += part[w][tid];
+    counts[h0 + tid] = v;
+  }
+}
+
+// argmax over counts with the lowest iteration on ties (the reference's strict '>' at T:673)
+__global__ void k_argmax(const int32_t* __restrict__ counts, int H, int32_t* __restrict__ best2) {
+  __shared__ long long part[4];
+  long long best = -1;
+  for (int h = threadIdx.x; h < H; h += blockDim.x) {
+    const long long key = ((long long)counts[h] << 32) | (long long)(0x7fffffff - h);
+    best = key > best ? key : best;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long t = __shfl_down(best, o, 64);
+    best = t > best ? t : best;
+  }
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) best = part[i] > best ? part[i] : best;
+    best2[0] = (int32_t)(0x7fffffff - (int32_t)(best & 0xffffffffll));
+    best2[1] = (int32_t)(best >> 32);
+  }
+}
+
+__global__ void k_sampson_mask(const double* __restrict__ xi, const double* __restrict__ xj, int n, const double* __restrict__ E,
+                               double thr, uint8_t* __restrict__ mask, int32_t* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int hit = 0;
+  if (i < n) {
+    const double err = sampson_eval(E[0], E[1], E[2], E[3], E[4], E[5], E[6], E[7], E[8], xi[2 * i], xi[2 * i + 1], xj[2 * i], xj[2 * i + 1]);
+    hit = (err < thr) ? 1 : 0;
+    mask[i] = (uint8_t)hit;
+  }
+  const unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int)__popcll(m));
+}
+
+extern "C" {
+
+int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, const int32_t* idx8, int H, double thr,
+                      int32_t* counts_out, int32_t* best_iter, int32_t* best_count, double* E_out) {
+  SFMX_REQUIRE(c, c && xi && xj && idx8 && n >= 8 && H > 0 && best_iter && best_count);
+  const size_t pb = (size_t)n * 16;
+  SFMX_HIP(c, c->d[0].ensure(pb));
+  SFMX_HIP(c, c->d[1].ensure(pb));
+  SFMX_HIP(c, c->d[2].ensure((size_t)H * 32));
+  SFMX_HIP(c, c->d[3].ensure((size_t)H * 72));
+  SFMX_HIP(c, c->d[4].ensure((size_t)H * 4 + 64));
+  SFMX_HIP(c, c->d[5].ensure(64));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xi, pb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[2].p, idx8, (size_t)H * 32, hipMemcpyHostToDevice, c->stream));
+  KernelTimer t(c);
+  t.start();
+  k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[2].as<int32_t>(), H, 120,
+                                                        c->d[3].as<double>());
+  k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[3].as<double>(), H,
+                                                              thr, c->d[4].as<int32_t>());
+  k_argmax<<<1, 256, 0, c->stream>>>(c->d[4].as<int32_t>(), H, c->d[5].as<int32_t>());
+  t.stop();
+  SFMX_HIP(c, hipGetLastError());
+  int32_t best2[2] = {0, 0};
+  SFMX_HIP(c, hipMemcpyAsync(best2, c->d[5].p, 8, hipMemcpyDeviceToHost, c->stream));
+  if (counts_out) SFMX_HIP(c, hipMemcpyAsync(counts_out, c->d[4].p, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
+  if (E_out) SFMX_HIP(c, hipMemcpyAsync(E_out, c->d[3].p, (size_t)H * 72, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  t.collect();
+  *best_iter = best2[0];
+  *best_count = best2[1];
+  return SFMX_OK;
+}
+
+// xi/xj are expected to be the arrays of the preceding sfmx_ransac_score call most of the time, but
+// the entry point is self-contained: it uploads them again (n*32 bytes).
+int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, const double* E9, double thr, uint8_t* mask_out,
+                      int32_t* count_out) {
+  SFMX_REQUIRE(c, c && xi && xj && E9 && mask_out && n > 0);
+  const size_t pb = (size_t)n * 16;
+  SFMX_HIP(c, c->d[0].ensure(pb));
+  SFMX_HIP(c, c->d[1].ensure(pb));
+  SFMX_HIP(c, c->d[6].ensure(128));
+  SFMX_HIP(c, c->d[7].ensure((size_t)n + 64));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xi, pb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[6].p, E9, 72, hipMemcpyHostToDevice, c->stream));
+  int32_t* d_cnt = reinterpret_cast<int32_t*>(c->d[6].as<char>() + 96);
+  SFMX_HIP(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+  k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[6].as<double>(), thr,
+                                                       c->d[7].as<uint8_t>(), d_cnt);
+  SFMX_HIP(c, hipGetLastError());
+  int32_t cnt = 0;
+  SFMX_HIP(c, hipMemcpyAsync(mask_out, c->d[7].p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  if (count_out) *count_out = cnt;
+  return SFMX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,124 @@
+// sfmx_internal.h — context, buffers and error plumbing behind include/sfmx.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../../include/sfmx.h"
+#include "sfmx_math.h"
+
+#define SFMX_MAX_LEVELS 8
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n < 4096 ? 4096 : n + n / 4;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n < 4096 ? 4096 : n + n / 4;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct sfmx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false;
+  double last_us = 0.0;
+  std::string err;
+  // reusable staging: a few independent device / pinned slabs
+  DevBuf d[8];
+  PinBuf h[4];
+};
+
+struct sfmx_pyramid {
+  int w = 0, h = 0, levels = 0;
+  uint8_t* base = nullptr;
+  size_t off[SFMX_MAX_LEVELS] = {0};
+  int lw[SFMX_MAX_LEVELS] = {0}, lh[SFMX_MAX_LEVELS] = {0};
+  size_t bytes = 0;
+};
+
+// by-value kernel argument describing one pyramid
+struct PyrDesc {
+  const uint8_t* px[SFMX_MAX_LEVELS];
+  int w[SFMX_MAX_LEVELS];
+  int h[SFMX_MAX_LEVELS];
+  int levels;
+};
+static inline PyrDesc make_desc(const sfmx_pyramid* p) {
+  PyrDesc d;
+  for (int l = 0; l < SFMX_MAX_LEVELS; l++) {
+    d.px[l] = (l < p->levels) ? p->base + p->off[l] : nullptr;
+    d.w[l] = (l < p->levels) ? p->lw[l] : 0;
+    d.h[l] = (l < p->levels) ? p->lh[l] : 0;
+  }
+  d.levels = p->levels;
+  return d;
+}
+
+int sfmx_fail(sfmx_ctx* ctx, int status, const char* what, hipError_t e);
+
+#define SFMX_HIP(ctx, call)                                                         \
+  do {                                                                              \
+    hipError_t e__ = (call);                                                        \
+    if (e__ != hipSuccess) return sfmx_fail((ctx), SFMX_ERR_HIP, #call, e__);       \
+  } while (0)
+
+#define SFMX_REQUIRE(ctx, cond)                                                     \
+  do {                                                                              \
+    if (!(cond)) return sfmx_fail((ctx), SFMX_ERR_INVALID, #cond, hipSuccess);      \
+  } while (0)
+
+// event timing of the dominant kernel of an API call (only when ctx->timing)
+struct KernelTimer {
+  sfmx_ctx* c;
+  explicit KernelTimer(sfmx_ctx* ctx) : c(ctx) {}
+  void start() {
+    if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+  }
+  void stop() {
+    if (c->timing) (void)hipEventRecord(c->ev1, c->stream);
+  }
+  void collect() {  // call after the stream has been synchronised
+    if (c->timing) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_us = (double)ms * 1000.0;
+    }
+  }
+};
