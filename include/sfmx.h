@@ -107,6 +107,9 @@ int sfmx_sampson_mask(sfmx_ctx* ctx, const double* xi, const double* xj, int n, 
 typedef struct sfmx_ba_problem sfmx_ba_problem;
 int sfmx_ba_create(sfmx_ctx* ctx, int W, int P, const double* X, const int32_t* obs_ptr,
                    const int32_t* obs_li, const double* obs_uv, sfmx_ba_problem** out);
+/* re-target an existing problem object at new data (device buffers are kept and only grow) */
+int sfmx_ba_reset(sfmx_ctx* ctx, sfmx_ba_problem* prob, int W, int P, const double* X, const int32_t* obs_ptr,
+                  const int32_t* obs_li, const double* obs_uv);
 void sfmx_ba_destroy(sfmx_ctx* ctx, sfmx_ba_problem* prob);
 int sfmx_ba_build(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, double fx, double fy,
                   double cx, double cy, double huber, double lambda, int damp, double* S_out,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "sfmx_last_kernel_us", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
     "sfmx_shi_tomasi_candidates", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",
-    "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
+    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt",
 ]
 

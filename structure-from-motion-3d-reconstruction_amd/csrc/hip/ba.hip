@@ -25,6 +25,7 @@
 
 struct sfmx_ba_problem {
   int W = 0, P = 0, R = 0, MS = 0;
+  DevBuf bufs[10];  // grow-only backing stores, so a problem object can be reset for every BA call
   double* X = nullptr;
   int32_t* obs_ptr = nullptr;
   int32_t* obs_li = nullptr;
@@ -239,10 +240,10 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, int MS, const d
 // ------------------------------------------------------------------------------------------ dense solve
 // status[0] = 0 ok, 1 singular (pivot < 1e-15).  A,b are read from global memory, x written.
 __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ Ain, const double* __restrict__ bin, int n,
-                                                     double* __restrict__ x, int* __restrict__ status) {
+                                                     double* __restrict__ x, int* __restrict__ status, double* gwork) {
   extern __shared__ __align__(16) double sm[];
   const int ld = n + 1;  // row stride (odd multiple of 8 B keeps column walks off one bank)
-  double* A = sm;                 // [n][ld]
+  double* A = gwork ? gwork : sm;   // [n][ld]: LDS when it fits, else a global working copy (L2-resident)
   double* bb = A + (size_t)n * ld;  // [n]
   double* fcol = bb + n;          // [n]
   __shared__ double red_v[4];
@@ -331,15 +332,24 @@ __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ 
 }
 
 static size_t solve_shmem(int n) { return ((size_t)n * (n + 1) + 2 * (size_t)n) * sizeof(double); }
-#define SOLVE_MAX_N 136
+#define SOLVE_LDS_MAX_N 141   // 141*142*8 + 2*141*8 + statics < 160 KiB
+#define SOLVE_MAX_N 4096
 
+// n <= 141: the whole system lives in LDS.  Larger systems (pose graphs) run the same kernel on a
+// global working copy in ctx->d[7]: correct and reference-ordered, single workgroup (the blocked
+// multi-CU solver for D ~ 1e4 is a "next" row).
 static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
   static bool attr_set = false;
   if (!attr_set) {
-    SFMX_HIP(c, hipFuncSetAttribute((const void*)k_solve_gauss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem(SOLVE_MAX_N)));
+    SFMX_HIP(c, hipFuncSetAttribute((const void*)k_solve_gauss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem(SOLVE_LDS_MAX_N)));
     attr_set = true;
   }
-  k_solve_gauss<<<1, 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus);
+  if (n <= SOLVE_LDS_MAX_N) {
+    k_solve_gauss<<<1, 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus, nullptr);
+  } else {
+    SFMX_HIP(c, c->d[7].ensure(solve_shmem(n)));
+    k_solve_gauss<<<1, 256, 0, c->stream>>>(dA, db, n, dx, dstatus, c->d[7].as<double>());
+  }
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;
 }
@@ -359,32 +369,21 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
 
 extern "C" {
 
-int sfmx_ba_create(sfmx_ctx* c, int W, int P, const double* X, const int32_t* obs_ptr, const int32_t* obs_li, const double* obs_uv,
-                   sfmx_ba_problem** out) {
-  SFMX_REQUIRE(c, c && out && W >= 1 && W <= BA_MAX_W && P >= 1 && X && obs_ptr && obs_li && obs_uv);
+int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X, const int32_t* obs_ptr, const int32_t* obs_li,
+                  const double* obs_uv) {
+  SFMX_REQUIRE(c, c && q && W >= 1 && W <= BA_MAX_W && P >= 1 && X && obs_ptr && obs_li && obs_uv);
   const int R = obs_ptr[P];
   SFMX_REQUIRE(c, R >= 0 && obs_ptr[0] == 0);
-  sfmx_ba_problem* q = new sfmx_ba_problem;
   q->W = W; q->P = P; q->R = R;
   q->MS = W < BA_MAX_OBS ? W : BA_MAX_OBS;
   const int D = 6 * W;
-  hipError_t e = hipSuccess;
-  auto alloc = [&](void** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n ? n : 8); };
-  alloc((void**)&q->X, (size_t)P * 24);
-  alloc((void**)&q->obs_ptr, (size_t)(P + 1) * 4);
-  alloc((void**)&q->obs_li, (size_t)R * 4);
-  alloc((void**)&q->obs_uv, (size_t)R * 16);
-  alloc((void**)&q->poses, (size_t)W * 96);
-  alloc((void**)&q->rec, (size_t)P * q->MS * BA_SLOT * 8);
-  alloc((void**)&q->slot_of, (size_t)P * W);
-  alloc((void**)&q->S, (size_t)D * D * 8);
-  alloc((void**)&q->b, (size_t)D * 8);
-  alloc((void**)&q->work, (size_t)D * 8 + 64);
-  if (e != hipSuccess) {
-    sfmx_ba_destroy(c, q);
-    return sfmx_fail(c, SFMX_ERR_HIP, "hipMalloc(ba problem)", e);
-  }
-  *out = q;
+  const size_t need[10] = {(size_t)P * 24, (size_t)(P + 1) * 4, (size_t)R * 4 + 8, (size_t)R * 16 + 8, (size_t)W * 96,
+                           (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8, (size_t)D * 8, (size_t)D * 8 + 64};
+  for (int i = 0; i < 10; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
+  q->X = q->bufs[0].as<double>(); q->obs_ptr = q->bufs[1].as<int32_t>(); q->obs_li = q->bufs[2].as<int32_t>();
+  q->obs_uv = q->bufs[3].as<double>(); q->poses = q->bufs[4].as<double>(); q->rec = q->bufs[5].as<double>();
+  q->slot_of = q->bufs[6].as<int8_t>(); q->S = q->bufs[7].as<double>(); q->b = q->bufs[8].as<double>();
+  q->work = q->bufs[9].as<double>();
   SFMX_HIP(c, hipMemcpyAsync(q->X, X, (size_t)P * 24, hipMemcpyHostToDevice, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(q->obs_ptr, obs_ptr, (size_t)(P + 1) * 4, hipMemcpyHostToDevice, c->stream));
   if (R > 0) {
@@ -395,12 +394,23 @@ int sfmx_ba_create(sfmx_ctx* c, int W, int P, const double* X, const int32_t* ob
   return SFMX_OK;
 }
 
+int sfmx_ba_create(sfmx_ctx* c, int W, int P, const double* X, const int32_t* obs_ptr, const int32_t* obs_li, const double* obs_uv,
+                   sfmx_ba_problem** out) {
+  SFMX_REQUIRE(c, c && out);
+  sfmx_ba_problem* q = new sfmx_ba_problem;
+  const int rc = sfmx_ba_reset(c, q, W, P, X, obs_ptr, obs_li, obs_uv);
+  if (rc != SFMX_OK) {
+    sfmx_ba_destroy(c, q);
+    return rc;
+  }
+  *out = q;
+  return SFMX_OK;
+}
+
 void sfmx_ba_destroy(sfmx_ctx* c, sfmx_ba_problem* q) {
   if (!q) return;
   if (c) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {q->X, q->obs_ptr, q->obs_li, q->obs_uv, q->poses, q->rec, q->slot_of, q->S, q->b, q->work};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  for (auto& b : q->bufs) b.release();
   delete q;
 }
 
@@ -435,7 +445,6 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
                  double lambda, double* dx_out) {
   SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
   const int D = 6 * q->W;
-  SFMX_REQUIRE(c, D <= SOLVE_MAX_N);
   KernelTimer t(c);
   int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t);
   if (rc) return rc;
@@ -452,7 +461,7 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
 
 int sfmx_solve_dense(sfmx_ctx* c, const double* A, const double* b, int n, double* x) {
   SFMX_REQUIRE(c, c && A && b && x && n >= 1);
-  if (n > SOLVE_MAX_N) return sfmx_fail(c, SFMX_ERR_UNSUPPORTED, "sfmx_solve_dense: n > 136 (LDS-resident solver)", hipSuccess);
+  if (n > SOLVE_MAX_N) return sfmx_fail(c, SFMX_ERR_UNSUPPORTED, "sfmx_solve_dense: n > 4096 (single-workgroup solver)", hipSuccess);
   const size_t nb = (size_t)n * n * 8;
   SFMX_HIP(c, c->d[0].ensure(nb));
   SFMX_HIP(c, c->d[1].ensure((size_t)n * 8));

@@ -1,0 +1,727 @@
+// pipeline.cpp — see pipeline.hpp.  Reference citations: T: = cpp/src/templering_sfm.cpp.
+#include "pipeline.hpp"
+
+#include "../hip/sfmx_math.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <sstream>
+
+namespace sfmx_host {
+
+namespace {
+using Clock = std::chrono::steady_clock;
+inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+void check(sfmx_ctx* ctx, int rc, const char* where) {
+  if (rc != SFMX_OK) throw SfmxFailure(rc, std::string("sfmx: ") + where + ": " + sfmx_last_error(ctx));
+}
+}  // namespace
+
+void MemoryFrames::load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) {
+  if (fi < 0 || fi >= n) throw std::runtime_error("frame index out of range");
+  const size_t off = (size_t)fi * (size_t)w * (size_t)h;
+  if (dev) check(ctx, sfmx_pyramid_set_device(ctx, pyr, dev + off), "pyramid_set_device");
+  else check(ctx, sfmx_pyramid_upload(ctx, pyr, host + off), "pyramid_upload");
+}
+
+// ------------------------------------------------------------------------------------------ tracker
+GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk)
+    : ctx_(ctx), cfg_(cfg), w_(w), h_(h), clk_(clk) {
+  levels_total_ = std::max(cfg.pyr_levels, extra_levels);
+  check(ctx_, sfmx_pyramid_create(ctx_, w, h, levels_total_, &prev_), "pyramid_create");
+  check(ctx_, sfmx_pyramid_create(ctx_, w, h, levels_total_, &cur_), "pyramid_create");
+}
+GpuTracker::~GpuTracker() {
+  sfmx_pyramid_destroy(ctx_, prev_);
+  sfmx_pyramid_destroy(ctx_, cur_);
+}
+
+std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist) {
+  const auto t0 = Clock::now();
+  int w = 0, h = 0;
+  sfmx_pyramid_level_size(pyr, 0, &w, &h);
+  const int cap = w * h;
+  if ((int)cand_xy_.size() < cap) { cand_xy_.resize((size_t)cap); cand_s_.resize((size_t)cap); }
+  int n = 0;
+  double maxv = 0;
+  check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &n, &maxv), "shi_tomasi_candidates");
+  if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
+  struct Cand { int x, y; double s; };
+  std::vector<Cand> cands((size_t)n);
+  for (int i = 0; i < n; i++) cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0xffffu), (int)(cand_xy_[(size_t)i] >> 16), cand_s_[(size_t)i]};
+  // same libstdc++ introsort, same input order, same predicate as T:286 => same permutation
+  std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s; });
+  // greedy min-distance pick (T:288-300).  "no accepted corner closer than min_dist" does not depend
+  // on the order in which accepted corners are visited, so a uniform grid replaces the O(N*K) scan.
+  std::vector<V2> out;
+  out.reserve((size_t)std::max(0, max_corners));
+  const int cell = std::max(1, min_dist);
+  const int gw = w / cell + 1, gh = h / cell + 1;
+  std::vector<std::vector<int>> grid((size_t)gw * gh);
+  const double md2 = (double)min_dist * min_dist;
+  for (const Cand& c : cands) {
+    bool ok = true;
+    const int cx = c.x / cell, cy = c.y / cell;
+    for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1) && ok; gy++)
+      for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1) && ok; gx++)
+        for (int idx : grid[(size_t)gy * gw + gx]) {
+          const double dx = out[(size_t)idx].x - c.x, dy = out[(size_t)idx].y - c.y;
+          if (dx * dx + dy * dy < md2) { ok = false; break; }
+        }
+    if (!ok) continue;
+    grid[(size_t)cy * gw + cx].push_back((int)out.size());
+    out.push_back(V2{double(c.x), double(c.y)});
+    if ((int)out.size() >= max_corners) break;
+  }
+  if (clk_) clk_->shi += since(t0);
+  return out;
+}
+
+void GpuTracker::reset(FrameSource& src, int fi) {
+  const auto t0 = Clock::now();
+  src.load(ctx_, fi, prev_);
+  if (clk_) clk_->upload += since(t0);
+  have_prev_ = true;
+  tracks_.clear();
+  for (const V2& p : shi_tomasi(prev_, cfg_.max_tracks, cfg_.quality, cfg_.min_distance)) tracks_.push_back({next_id_++, p});
+}
+
+void GpuTracker::track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
+                             std::vector<std::uint8_t>& keep) {
+  const int n = (int)p0.size();
+  fwd.resize((size_t)n);
+  keep.resize((size_t)n);
+  if (n == 0) return;
+  static_assert(sizeof(V2) == 16, "V2 must be two packed doubles");
+  sfmx_klt_cfg kc{cfg_.pyr_levels, cfg_.win_radius, cfg_.iters, cfg_.fb_thresh};
+  std::uint64_t steps = 0;
+  const auto t0 = Clock::now();
+  check(ctx_, sfmx_klt_track(ctx_, a, b, &p0[0].x, n, &kc, &fwd[0].x, nullptr, keep.data(), &steps), "klt_track");
+  if (clk_) {
+    clk_->klt += since(t0);
+    clk_->klt_kernel_us += sfmx_last_kernel_us(ctx_);
+    clk_->lk_steps += steps;
+    clk_->tracks_in += (std::uint64_t)n;
+    clk_->klt_calls++;
+  }
+}
+
+StepOut GpuTracker::step(FrameSource& src, int fi) {
+  if (!have_prev_ || tracks_.empty()) {  // T:341-344
+    reset(src, fi);
+    return {};
+  }
+  auto t0 = Clock::now();
+  src.load(ctx_, fi, cur_);  // pyr1; pyr0 is the cached pyramid of prev_ (identical to rebuilding it, T:345)
+  if (clk_) clk_->upload += since(t0);
+  std::vector<V2> p0(tracks_.size()), fwd;
+  std::vector<std::uint8_t> keep;
+  for (size_t i = 0; i < tracks_.size(); i++) p0[i] = tracks_[i].p;
+  track_pairs(prev_, cur_, p0, fwd, keep);
+  StepOut out;
+  std::vector<Track> kept;
+  kept.reserve(tracks_.size());
+  out.prev_pts.reserve(tracks_.size());
+  out.cur_pts.reserve(tracks_.size());
+  out.ids.reserve(tracks_.size());
+  for (size_t i = 0; i < tracks_.size(); i++) {
+    if (!keep[i]) continue;  // T:362
+    kept.push_back({tracks_[i].id, fwd[i]});
+    out.prev_pts.push_back(p0[i]);
+    out.cur_pts.push_back(fwd[i]);
+    out.ids.push_back(tracks_[i].id);
+  }
+  std::swap(prev_, cur_);  // prev_ = gray (T:370)
+  tracks_ = std::move(kept);
+  if ((int)tracks_.size() < cfg_.min_tracks) {  // replenish (T:374-389)
+    const int need = cfg_.max_tracks - (int)tracks_.size();
+    const auto pts = shi_tomasi(prev_, need * 3, cfg_.quality, cfg_.min_distance);
+    t0 = Clock::now();
+    // distance filter against all live tracks (incl. the ones appended here): existence test, so a
+    // grid over track positions gives the same answer as the reference's linear scan.
+    const int cell = std::max(1, cfg_.min_distance);
+    const int gw = w_ / cell + 3, gh = h_ / cell + 3;  // one guard cell around the image
+    std::vector<std::vector<int>> grid((size_t)gw * gh);
+    auto cell_of = [&](double v, int lim) -> int {
+      if (!(v > -(double)cell && v < (double)(lim + cell))) return -1;  // farther than min_distance from any pixel (or NaN)
+      return (int)std::floor(v / cell) + 1;
+    };
+    auto insert = [&](int ti) {
+      const int gx = cell_of(tracks_[(size_t)ti].p.x, w_), gy = cell_of(tracks_[(size_t)ti].p.y, h_);
+      if (gx < 0 || gy < 0 || gx >= gw || gy >= gh) return;
+      grid[(size_t)gy * gw + gx].push_back(ti);
+    };
+    for (int i = 0; i < (int)tracks_.size(); i++) insert(i);
+    const double md2 = (double)cfg_.min_distance * cfg_.min_distance;
+    for (const V2& p : pts) {
+      bool ok = true;
+      const int cx = (int)p.x / cell + 1, cy = (int)p.y / cell + 1;
+      for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1) && ok; gy++)
+        for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1) && ok; gx++)
+          for (int ti : grid[(size_t)gy * gw + gx]) {
+            const double dx = tracks_[(size_t)ti].p.x - p.x, dy = tracks_[(size_t)ti].p.y - p.y;
+            if (dx * dx + dy * dy < md2) { ok = false; break; }
+          }
+      if (!ok) continue;
+      tracks_.push_back({next_id_++, p});
+      insert((int)tracks_.size() - 1);
+      if ((int)tracks_.size() >= cfg_.max_tracks) break;
+    }
+    if (clk_) clk_->shi += since(t0);
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------ RANSAC
+std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
+                                         double thr, int min_inliers, StageClock* clk) {
+  if (pi.size() < 8) return std::nullopt;  // T:648
+  const auto t0 = Clock::now();
+  Mat3 Kinv;
+  if (!invert_K(K, Kinv)) throw std::runtime_error("Singular K");  // T:474
+  const int n = (int)pi.size();
+  std::vector<double> xi((size_t)2 * n), xj((size_t)2 * n);
+  for (int i = 0; i < n; i++) {
+    const V2 a = norm_point(Kinv, pi[(size_t)i]), b = norm_point(Kinv, pj[(size_t)i]);
+    xi[2 * (size_t)i] = a.x; xi[2 * (size_t)i + 1] = a.y;
+    xj[2 * (size_t)i] = b.x; xj[2 * (size_t)i + 1] = b.y;
+  }
+  // the reference draws 8 indices per iteration from mt19937(12345) (T:657-665); pre-draw the stream
+  std::vector<std::int32_t> idx8((size_t)8 * std::max(iters, 0));
+  {
+    Mt19937 rng(12345);
+    for (size_t k = 0; k < idx8.size(); k++) idx8[k] = rng.below((std::uint32_t)n);
+  }
+  if (iters <= 0) return std::nullopt;
+  std::vector<std::int32_t> counts((size_t)iters);
+  std::int32_t best_iter = -1, best_count = 0;
+  check(ctx, sfmx_ransac_score(ctx, xi.data(), xj.data(), n, idx8.data(), iters, thr, counts.data(), &best_iter, &best_count, nullptr),
+        "ransac_score");
+  if (clk) {
+    clk->ransac_kernel_us += sfmx_last_kernel_us(ctx);
+    clk->ransac_calls++;
+    clk->ransac_points += (std::uint64_t)n;
+  }
+  // Device hypotheses rank the iterations; the winner's E is re-derived with the platform libm (so it
+  // is the reference's E bit for bit) and its mask recomputed from that E.  Iterations whose device
+  // count is within 2 of the maximum are verified the same way, so a last-bit disagreement between
+  // the device ranking E and the reference E cannot change which iteration wins.
+  std::optional<RelPose> result;
+  if (best_count > 0) {
+    int win_iter = -1, win_count = -1;
+    Mat3 winE;
+    std::vector<std::uint8_t> mask((size_t)n), win_mask;
+    for (int it = 0; it < iters; ++it) {
+      if (counts[(size_t)it] < best_count - 2 || counts[(size_t)it] <= 0) continue;
+      const Mat3 E = eight_point_E(xi.data(), xj.data(), &idx8[(size_t)8 * it]);
+      std::int32_t cnt = 0;
+      check(ctx, sfmx_sampson_mask(ctx, xi.data(), xj.data(), n, E.a, thr, mask.data(), &cnt), "sampson_mask");
+      if (clk) clk->ransac_verified++;
+      if (cnt > win_count) {  // strict '>' keeps the lowest iteration (T:673)
+        win_count = cnt;
+        win_iter = it;
+        winE = E;
+        win_mask = mask;
+      }
+    }
+    if (win_iter >= 0 && win_count >= min_inliers) {  // T:678
+      RelPose rp;
+      rp.best_iter = win_iter;
+      for (int i = 0; i < n; i++)
+        if (win_mask[(size_t)i]) rp.inliers.push_back(i);
+      decompose_E(winE, xi.data(), xj.data(), rp.inliers, rp.R_ji, rp.t_ji);
+      result = std::move(rp);
+    }
+  }
+  if (clk) clk->ransac += since(t0);
+  return result;
+}
+
+// ------------------------------------------------------------------------------------------ map
+int MapState::add(int tid, V3 Xw) {
+  const int pid = next_pid++;
+  MapPoint mp;
+  mp.pid = pid;
+  mp.tid = tid;
+  mp.Xw = Xw;
+  pts.emplace(pid, mp);
+  tid2pid.emplace(tid, pid);
+  return pid;
+}
+void MapState::add_obs(int tid, int kf_id, V2 uv) {
+  auto it = tid2pid.find(tid);
+  if (it == tid2pid.end()) return;
+  pts[it->second].obs.push_back({kf_id, uv});
+}
+
+// ------------------------------------------------------------------------------------------ BA
+GpuBundleAdjuster::~GpuBundleAdjuster() { sfmx_ba_destroy(ctx_, prob_); }
+
+void GpuBundleAdjuster::run(const Mat3& K, std::vector<Keyframe>& kfs, MapState& map, const BAConfig& cfg) {
+  const int N = (int)kfs.size();
+  if (N < 2) return;
+  const int w0 = std::max(0, N - cfg.window), W = N - w0;
+  if (W < 2) return;
+  const auto t0 = Clock::now();
+  std::unordered_map<int, int> kf2local;
+  kf2local.reserve((size_t)W);
+  for (int li = 0; li < W; ++li) kf2local.emplace(kfs[(size_t)(w0 + li)].kf_id, li);
+  // points with >= 2 window observations, in the map's iteration order (T:871-882)
+  std::vector<double> X, uv;
+  std::vector<std::int32_t> optr{0}, oli;
+  int P = 0;
+  for (auto& kv : map.pts) {
+    const size_t mark = oli.size();
+    for (const auto& ob : kv.second.obs) {
+      auto it = kf2local.find(ob.first);
+      if (it == kf2local.end()) continue;
+      oli.push_back(it->second);
+      uv.push_back(ob.second.x);
+      uv.push_back(ob.second.y);
+    }
+    if ((int)(oli.size() - mark) < 2) {
+      oli.resize(mark);
+      uv.resize(2 * mark);
+      continue;
+    }
+    X.push_back(kv.second.Xw.x); X.push_back(kv.second.Xw.y); X.push_back(kv.second.Xw.z);
+    optr.push_back((std::int32_t)oli.size());
+    if (++P >= cfg.max_points) break;
+  }
+  if (P == 0) return;
+  if (W > 64) throw SfmxFailure(SFMX_ERR_UNSUPPORTED, "ba.window > 64 is not supported");
+  if (!prob_) check(ctx_, sfmx_ba_create(ctx_, W, P, X.data(), optr.data(), oli.data(), uv.data(), &prob_), "ba_create");
+  else check(ctx_, sfmx_ba_reset(ctx_, prob_, W, P, X.data(), optr.data(), oli.data(), uv.data()), "ba_reset");
+  const int D = 6 * W;
+  std::vector<double> poses((size_t)W * 12), dx((size_t)D);
+  if (clk_) clk_->ba_calls++;
+  for (int it = 0; it < cfg.iters; ++it) {
+    for (int li = 0; li < W; li++) {
+      Mat3 R;
+      V3 t;
+      inv_wc(kfs[(size_t)(w0 + li)].pose, R, t);
+      std::memcpy(&poses[(size_t)12 * li], R.a, 72);
+      poses[(size_t)12 * li + 9] = t.x; poses[(size_t)12 * li + 10] = t.y; poses[(size_t)12 * li + 11] = t.z;
+    }
+    const int rc = sfmx_ba_step(ctx_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), cfg.huber_delta, cfg.lambda, dx.data());
+    if (clk_) { clk_->ba_kernel_us += sfmx_last_kernel_us(ctx_); clk_->ba_iters++; }
+    if (rc == SFMX_ERR_SINGULAR) break;  // T:1076-1078: ill-conditioned -> skip the rest of BA
+    check(ctx_, rc, "ba_step");
+    for (int li = 1; li < W; ++li) {  // T:1081-1095
+      const V3 w{dx[(size_t)6 * li], dx[(size_t)6 * li + 1], dx[(size_t)6 * li + 2]};
+      const V3 v{dx[(size_t)6 * li + 3], dx[(size_t)6 * li + 4], dx[(size_t)6 * li + 5]};
+      Mat3 R;
+      V3 t;
+      inv_wc(kfs[(size_t)(w0 + li)].pose, R, t);
+      const Mat3 R2 = so3_exp(w) * R;
+      const V3 t2 = t + v;
+      const Mat3 Rcw = transpose(R2);
+      kfs[(size_t)(w0 + li)].pose.R = Rcw;
+      kfs[(size_t)(w0 + li)].pose.t = -(Rcw * t2);
+    }
+  }
+  if (clk_) clk_->ba += since(t0);
+}
+
+// T:1131-1197 (assembly on the host, solve through the C ABI)
+bool posegraph_optimize_centers(sfmx_ctx* ctx, std::vector<Keyframe>& kfs, const std::vector<PGEdge>& edges) {
+  const int N = (int)kfs.size();
+  if (N < 2 || edges.empty()) return false;
+  const int D = 3 * N;
+  std::vector<double> H((size_t)D * D, 0.0), g((size_t)D, 0.0), dc((size_t)D, 0.0);
+  auto addI = [&](int a, int b, double s) { for (int d = 0; d < 3; d++) H[(size_t)(3 * a + d) * D + (3 * b + d)] += s; };
+  for (const PGEdge& e : edges) {
+    if (e.i < 0 || e.j < 0 || e.i >= N || e.j >= N) continue;
+    const V3 Ci = kfs[(size_t)e.i].pose.t, Cj = kfs[(size_t)e.j].pose.t;
+    const V3 dest = Cj - Ci;
+    const V3 td = -(transpose(e.R_ji) * e.t_ji);
+    const V3 dir = unit(kfs[(size_t)e.i].pose.R * td);
+    const double L = std::max(1e-6, norm(dest));
+    const V3 dm = L * dir;
+    const V3 r = (Cj - Ci) - dm;
+    const double w = e.is_loop ? 2.0 : 1.0;
+    addI(e.i, e.i, w); addI(e.j, e.j, w); addI(e.i, e.j, -w); addI(e.j, e.i, -w);
+    g[(size_t)3 * e.i + 0] += w * (-r.x); g[(size_t)3 * e.i + 1] += w * (-r.y); g[(size_t)3 * e.i + 2] += w * (-r.z);
+    g[(size_t)3 * e.j + 0] += w * (r.x);  g[(size_t)3 * e.j + 1] += w * (r.y);  g[(size_t)3 * e.j + 2] += w * (r.z);
+  }
+  for (int d = 0; d < 3; d++) { H[(size_t)d * D + d] += 1e9; g[(size_t)d] = 0.0; }
+  const int rc = sfmx_solve_dense(ctx, H.data(), g.data(), D, dc.data());
+  if (rc == SFMX_ERR_SINGULAR) return false;
+  check(ctx, rc, "solve_dense(pose graph)");
+  for (int i = 1; i < N; i++) {
+    kfs[(size_t)i].pose.t.x += dc[(size_t)3 * i];
+    kfs[(size_t)i].pose.t.y += dc[(size_t)3 * i + 1];
+    kfs[(size_t)i].pose.t.z += dc[(size_t)3 * i + 2];
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------ main loop
+namespace {
+
+// global_desc_32 (T:1100-1122): the repeated downsample2 chain IS the device pyramid, so only the
+// first level with w<=32 && h<=32 is downloaded.
+int desc_level(int w, int h) {
+  int l = 0;
+  while (w > 32 || h > 32) { w /= 2; h /= 2; l++; }
+  return l;
+}
+std::vector<float> global_desc_32(sfmx_ctx* ctx, sfmx_pyramid* pyr, int level) {
+  int dw = 0, dh = 0;
+  sfmx_pyramid_level_size(pyr, level, &dw, &dh);
+  std::vector<std::uint8_t> d((size_t)std::max(1, dw * dh));
+  check(ctx, sfmx_pyramid_download_level(ctx, pyr, level, d.data()), "pyramid_download_level");
+  std::vector<float> v;
+  v.reserve(1024);
+  double mean = 0.0;
+  for (int y = 0; y < 32; y++)
+    for (int x = 0; x < 32; x++) {
+      const int sx = std::min(dw - 1, (int)std::round((double)x * (dw - 1) / 31.0));
+      const int sy = std::min(dh - 1, (int)std::round((double)y * (dh - 1) / 31.0));
+      const float val = (float)d[(size_t)sy * dw + sx];
+      v.push_back(val);
+      mean += val;
+    }
+  mean /= (32.0 * 32.0);
+  double n2 = 0.0;
+  for (float& x : v) { x = (float)(x - (float)mean); n2 += (double)x * (double)x; }
+  const double inv = 1.0 / std::sqrt(n2 + 1e-12);
+  for (float& x : v) x = (float)(x * inv);
+  return v;
+}
+float dot_desc(const std::vector<float>& a, const std::vector<float>& b) {
+  float s = 0.0f;
+  const size_t n = std::min(a.size(), b.size());
+  for (size_t i = 0; i < n; i++) s += a[i] * b[i];
+  return s;
+}
+
+}  // namespace
+
+void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>& meta, const Mat3& K, const PipelineConfig& cfg,
+                  PipelineResult& out, void (*echo)(const std::string&)) {
+  const auto t_all = Clock::now();
+  StageClock& clk = out.clock;
+  const int w = src.width(), h = src.height();
+  const int dlevel = desc_level(w, h);
+  if (dlevel + 1 > 8 || cfg.klt.pyr_levels > 8) throw SfmxFailure(SFMX_ERR_UNSUPPORTED, "image too large for an 8-level pyramid");
+  GpuTracker tracker(ctx, cfg.klt, w, h, dlevel + 1, &clk);
+  GpuBundleAdjuster ba(ctx, &clk);
+  sfmx_pyramid* old_pyr = nullptr;  // loop-closure verification image (T:1834)
+  struct Guard { sfmx_ctx* c; sfmx_pyramid** p; ~Guard() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard{ctx, &old_pyr};
+
+  Pose cur;
+  std::vector<Keyframe>& kfs = out.kfs;
+  MapState& map = out.map;
+  std::vector<PGEdge>& edges = out.edges;
+  std::vector<std::vector<float>> kf_desc;
+  std::unordered_map<int, std::vector<std::pair<int, V2>>> track_hist;
+  int last_kf_frame = -999999;
+  const int frames = cfg.frames;
+  std::ostringstream so;
+  auto emit = [&](int fi) {
+    std::ostringstream line;
+    line << "frame " << (fi + 1) << "/" << frames << " | keyframes=" << kfs.size() << " | map_points=" << map.pts.size() << "\n";
+    so << line.str();
+    if (echo) echo(line.str());
+  };
+
+  for (int fi = 0; fi < std::min(frames, src.count()); ++fi) {
+    StepOut step = tracker.step(src, fi);
+    if (step.prev_pts.empty()) {  // first keyframe (T:1715-1733)
+      Keyframe kf;
+      kf.kf_id = (int)kfs.size();
+      kf.frame_idx = fi;
+      kf.img_name = meta[(size_t)fi].name;
+      kf.pose = cur;
+      kf_desc.push_back(global_desc_32(ctx, tracker.current(), dlevel));
+      for (const Track& tr : tracker.tracks()) {
+        kf.obs.emplace(tr.id, tr.p);
+        track_hist[tr.id].push_back({kf.kf_id, tr.p});
+      }
+      kfs.push_back(std::move(kf));
+      last_kf_frame = fi;
+      emit(fi);
+      continue;
+    }
+    const std::vector<V2>& p_i = step.prev_pts;
+    const std::vector<V2>& p_j = step.cur_pts;
+    auto rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk);  // T:1739
+    int inliers = 0;
+    double parallax = 0.0;
+    if (rel) {
+      inliers = (int)rel->inliers.size();
+      std::vector<double> ds;
+      ds.reserve(rel->inliers.size());
+      for (int idx : rel->inliers) ds.push_back(std::hypot(p_j[(size_t)idx].x - p_i[(size_t)idx].x, p_j[(size_t)idx].y - p_i[(size_t)idx].y));
+      if (!ds.empty()) {
+        std::nth_element(ds.begin(), ds.begin() + (long)(ds.size() / 2), ds.end());
+        parallax = ds[ds.size() / 2];
+      }
+      cur = compose_right_inv(cur, rel->R_ji, rel->t_ji);  // T:1762
+    }
+    bool make_kf = true;  // T:1700-1704,1765
+    if (!kfs.empty() && rel.has_value()) {
+      if (fi - last_kf_frame < cfg.kf_min_gap) make_kf = false;
+      else if (inliers < cfg.kf_min_inliers) make_kf = true;
+      else make_kf = parallax >= cfg.kf_parallax_px;
+    }
+    if (make_kf) {
+      Keyframe kf;
+      kf.kf_id = (int)kfs.size();
+      kf.frame_idx = fi;
+      kf.img_name = meta[(size_t)fi].name;
+      kf.pose = cur;
+      const auto new_desc = global_desc_32(ctx, tracker.current(), dlevel);
+      for (const Track& tr : tracker.tracks()) {
+        kf.obs.emplace(tr.id, tr.p);
+        track_hist[tr.id].push_back({kf.kf_id, tr.p});
+        if (map.has(tr.id)) map.add_obs(tr.id, kf.kf_id, tr.p);
+      }
+      if (!kfs.empty()) {  // sequential pose-graph edge (T:1782-1798)
+        const Keyframe& prev_kf = kfs.back();
+        std::vector<V2> ei, ej;
+        ei.reserve(1200);
+        ej.reserve(1200);
+        for (const auto& kv : kf.obs) {
+          auto itp = prev_kf.obs.find(kv.first);
+          if (itp == prev_kf.obs.end()) continue;
+          ei.push_back(itp->second);
+          ej.push_back(kv.second);
+        }
+        if (ei.size() >= 80) {
+          auto eopt = find_E_ransac_gpu(ctx, K, ei, ej, 2500, 1e-3, 60, &clk);
+          if (eopt) edges.push_back(PGEdge{prev_kf.kf_id, kf.kf_id, eopt->R_ji, eopt->t_ji, (int)eopt->inliers.size(), false});
+        }
+      }
+      if (kfs.size() >= 1) {  // triangulate new points (T:1801-1813)
+        const auto th0 = Clock::now();
+        for (auto& kv : track_hist) {
+          const int tid = kv.first;
+          auto& hist = kv.second;
+          if (map.has(tid) || hist.size() < 2) continue;
+          const int id0 = hist.front().first, idl = hist.back().first;
+          if (id0 == idl) continue;
+          // Quirk Q12: the reference indexes kfs[idl] at T:1809 before the keyframe under
+          // construction is pushed (T:1815), i.e. one past the end of the vector whenever idl is the
+          // new keyframe — undefined behaviour whose result is heap garbage.  The defined reading is
+          // used here: the new keyframe's own pose.
+          const Pose& pl = (idl < (int)kfs.size()) ? kfs[(size_t)idl].pose : kf.pose;
+          V3 Xw;
+          if (!triangulate_dlt(K, kfs[(size_t)id0].pose, pl, hist.front().second, hist.back().second, Xw)) throw std::runtime_error("Singular K");
+          map.add(tid, Xw);
+          for (const auto& ob : hist) map.add_obs(tid, ob.first, ob.second);
+        }
+        clk.host += since(th0);
+      }
+      kfs.push_back(std::move(kf));
+      kf_desc.push_back(new_desc);
+      last_kf_frame = fi;
+      ba.run(K, kfs, map, cfg.ba);  // T:1820
+
+      // loop closure (T:1822-1866)
+      const int new_kf_id = kfs.back().kf_id;
+      int best_id = -1;
+      float best_score = 0.0f;
+      for (int kk = 0; kk < (int)kfs.size() - 6; ++kk) {
+        const float s = dot_desc(kf_desc[(size_t)kk], new_desc);
+        if (s > best_score) { best_score = s; best_id = kk; }
+      }
+      if (best_id >= 0 && best_score > 0.94f) {
+        const Keyframe& old_kf = kfs[(size_t)best_id];
+        if (!old_pyr) check(ctx, sfmx_pyramid_create(ctx, w, h, tracker.levels_total(), &old_pyr), "pyramid_create");
+        src.load(ctx, old_kf.frame_idx, old_pyr);
+        LKConfig lc = cfg.klt;
+        lc.max_tracks = 1200;
+        lc.min_tracks = 600;
+        const auto pts0 = tracker.shi_tomasi(old_pyr, lc.max_tracks, lc.quality, lc.min_distance);
+        std::vector<V2> fwd;
+        std::vector<std::uint8_t> keep;
+        tracker.track_pairs(old_pyr, tracker.current(), pts0, fwd, keep);
+        std::vector<V2> li, lj;
+        for (size_t i = 0; i < pts0.size(); i++) {
+          if (!keep[i]) continue;
+          li.push_back(pts0[i]);
+          lj.push_back(fwd[i]);
+        }
+        if (li.size() >= 120) {
+          auto lopt = find_E_ransac_gpu(ctx, K, li, lj, 4000, 2e-3, 80, &clk);
+          if (lopt && (int)lopt->inliers.size() >= 100) {
+            edges.push_back(PGEdge{old_kf.kf_id, new_kf_id, lopt->R_ji, lopt->t_ji, (int)lopt->inliers.size(), true});
+            (void)posegraph_optimize_centers(ctx, kfs, edges);
+            ba.run(K, kfs, map, cfg.ba);
+          }
+        }
+      }
+    }
+    emit(fi);
+  }
+  out.log = so.str();
+  clk.total = since(t_all);
+}
+
+void write_outputs(const std::string& out_dir, const PipelineConfig& cfg, const std::vector<FrameMeta>& meta, PipelineResult& out) {
+  namespace fs = std::filesystem;
+  const fs::path dir(out_dir);
+  fs::create_directories(dir);
+  {
+    std::ofstream f(dir / "keyframes_camera_centers.csv");  // T:1463-1475
+    f << "kf_id,frame_idx,image,x,y,z,lat,lon\n";
+    for (const Keyframe& kf : out.kfs) {
+      const FrameMeta& m = meta[(size_t)kf.frame_idx];
+      f << kf.kf_id << "," << kf.frame_idx << "," << kf.img_name << "," << kf.pose.t.x << "," << kf.pose.t.y << "," << kf.pose.t.z << ","
+        << (m.has_ang ? m.lat : 0.0) << "," << (m.has_ang ? m.lon : 0.0) << "\n";
+    }
+  }
+  {
+    std::ofstream f(dir / "posegraph_edges.csv");  // T:1199-1209
+    f << "i,j,rvec_x,rvec_y,rvec_z,t_x,t_y,t_z,inliers,is_loop\n";
+    for (const PGEdge& e : out.edges) {
+      const V3 rv = so3_log(e.R_ji);
+      f << e.i << "," << e.j << "," << rv.x << "," << rv.y << "," << rv.z << "," << e.t_ji.x << "," << e.t_ji.y << "," << e.t_ji.z << ","
+        << e.inliers << "," << (e.is_loop ? 1 : 0) << "\n";
+    }
+  }
+  if (cfg.export_pointcloud) {  // T:1215-1224,1878-1883
+    const fs::path p = dir / "templeRing_sparse_points.ply";
+    std::ofstream f(p);
+    if (!f) throw std::runtime_error("Failed to write: " + p.string());
+    f << "ply\nformat ascii 1.0\n";
+    f << "element vertex " << out.map.pts.size() << "\n";
+    f << "property float x\nproperty float y\nproperty float z\nend_header\n";
+    for (const auto& kv : out.map.pts) f << kv.second.Xw.x << " " << kv.second.Xw.y << " " << kv.second.Xw.z << "\n";
+  }
+  std::ostringstream so;
+  so << "\n=== Summary ===\n";
+  so << "Keyframes: " << out.kfs.size() << "\n";
+  so << "Map points: " << out.map.pts.size() << "\n";
+  so << "Outputs: " << dir << "\n";
+  out.log += so.str();
+}
+
+}  // namespace sfmx_host
+
+// ============================================================================================ C ABI
+// Used by bench.py / tests through ctypes (libsfmx_host.so).  Plain pointers and sizes only.
+extern "C" {
+
+struct sfmx_pipeline_cfg {
+  int frames, export_pointcloud;
+  int max_tracks, min_tracks;
+  double quality;
+  int min_distance, pyr_levels, win_radius, klt_iters;
+  double fb_thresh;
+  int kf_min_gap, kf_min_inliers;
+  double kf_parallax_px;
+  int ba_window, ba_iters, ba_max_points;
+  double ba_huber, ba_lambda;
+};
+struct sfmx_pipeline_stats {
+  int n_keyframes, n_points, n_edges, n_frames;
+  double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host;
+  double us_klt_kernel, us_ransac_kernel, us_ba_kernel, us_shi_kernel;
+  unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified;
+};
+
+// images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
+// out_dir may be NULL (no files).  centres_out (optional) [n_keyframes<=cap][3].
+int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void* images_dev, int n_images, int w, int h,
+                      const char* const* names, const double* K9, const double* lat, const double* lon, const std::uint8_t* has_ang,
+                      const sfmx_pipeline_cfg* cfg, const char* out_dir, char* log, int log_cap, sfmx_pipeline_stats* stats,
+                      double* centres_out, int centres_cap) {
+  using namespace sfmx_host;
+  if (!ctx || !cfg || !K9 || (!images_host && !images_dev) || n_images <= 0) return SFMX_ERR_INVALID;
+  try {
+    MemoryFrames src;
+    src.host = images_host;
+    src.dev = static_cast<const std::uint8_t*>(images_dev);
+    src.n = n_images; src.w = w; src.h = h;
+    std::vector<FrameMeta> meta((size_t)n_images);
+    for (int i = 0; i < n_images; i++) {
+      meta[(size_t)i].name = names ? names[i] : ("frame" + std::to_string(i));
+      meta[(size_t)i].has_ang = has_ang ? has_ang[i] != 0 : false;
+      meta[(size_t)i].lat = lat ? lat[i] : 0.0;
+      meta[(size_t)i].lon = lon ? lon[i] : 0.0;
+    }
+    Mat3 K;
+    std::memcpy(K.a, K9, 72);
+    PipelineConfig pc;
+    pc.frames = cfg->frames;
+    pc.export_pointcloud = cfg->export_pointcloud != 0;
+    pc.klt.max_tracks = cfg->max_tracks; pc.klt.min_tracks = cfg->min_tracks; pc.klt.quality = cfg->quality;
+    pc.klt.min_distance = cfg->min_distance; pc.klt.pyr_levels = cfg->pyr_levels; pc.klt.win_radius = cfg->win_radius;
+    pc.klt.iters = cfg->klt_iters; pc.klt.fb_thresh = cfg->fb_thresh;
+    pc.kf_min_gap = cfg->kf_min_gap; pc.kf_min_inliers = cfg->kf_min_inliers; pc.kf_parallax_px = cfg->kf_parallax_px;
+    pc.ba.window = cfg->ba_window; pc.ba.iters = cfg->ba_iters; pc.ba.max_points = cfg->ba_max_points;
+    pc.ba.huber_delta = cfg->ba_huber; pc.ba.lambda = cfg->ba_lambda;
+    PipelineResult res;
+    run_pipeline(ctx, src, meta, K, pc, res);
+    if (out_dir) write_outputs(out_dir, pc, meta, res);
+    if (log && log_cap > 0) std::snprintf(log, (size_t)log_cap, "%s", res.log.c_str());
+    if (stats) {
+      const StageClock& c = res.clock;
+      *stats = sfmx_pipeline_stats{(int)res.kfs.size(), (int)res.map.pts.size(), (int)res.edges.size(), std::min(pc.frames, n_images),
+                                   c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host,
+                                   c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
+                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified};
+    }
+    if (centres_out)
+      for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {
+        centres_out[3 * k] = res.kfs[(size_t)k].pose.t.x;
+        centres_out[3 * k + 1] = res.kfs[(size_t)k].pose.t.y;
+        centres_out[3 * k + 2] = res.kfs[(size_t)k].pose.t.z;
+      }
+    return SFMX_OK;
+  } catch (const sfmx_host::SfmxFailure& e) {
+    if (log && log_cap > 0) std::snprintf(log, (size_t)log_cap, "ERROR: %s\n", e.what());
+    return e.status;
+  } catch (const std::exception& e) {
+    if (log && log_cap > 0) std::snprintf(log, (size_t)log_cap, "ERROR: %s\n", e.what());
+    return SFMX_ERR_INVALID;
+  }
+}
+
+// host-side math self-checks used by the CPU test-suite (no device involved)
+void sfmx_host_eight_point_E(const double* xn, const double* yn, const int* idx8, double* E9) {
+  const sfmx_host::Mat3 E = sfmx_host::eight_point_E(xn, yn, idx8);
+  std::memcpy(E9, E.a, 72);
+}
+void sfmx_host_uniform_draws(unsigned seed, int n, int count, int* out) {
+  sfmx_host::Mt19937 g(seed);
+  for (int i = 0; i < count; i++) out[i] = g.below((std::uint32_t)n);
+}
+void sfmx_host_decompose_E(const double* E9, const double* xi, const double* xj, const int* inl, int n_inl, double* R9, double* t3) {
+  sfmx_host::Mat3 E, R;
+  std::memcpy(E.a, E9, 72);
+  sfmx_host::V3 t;
+  std::vector<int> v(inl, inl + n_inl);
+  sfmx_host::decompose_E(E, xi, xj, v, R, t);
+  std::memcpy(R9, R.a, 72);
+  t3[0] = t.x; t3[1] = t.y; t3[2] = t.z;
+}
+void sfmx_host_triangulate_dlt(const double* K9, const double* Ri, const double* ti, const double* Rj, const double* tj, const double* ui,
+                               const double* uj, double* X3) {
+  sfmx_host::Mat3 K;
+  std::memcpy(K.a, K9, 72);
+  sfmx_host::Pose a, b;
+  std::memcpy(a.R.a, Ri, 72); a.t = {ti[0], ti[1], ti[2]};
+  std::memcpy(b.R.a, Rj, 72); b.t = {tj[0], tj[1], tj[2]};
+  sfmx_host::V3 X;
+  sfmx_host::triangulate_dlt(K, a, b, {ui[0], ui[1]}, {uj[0], uj[1]}, X);
+  X3[0] = X.x; X3[1] = X.y; X3[2] = X.z;
+}
+void sfmx_host_so3(const double* w3, double* R9, double* log3) {
+  const sfmx_host::Mat3 R = sfmx_host::so3_exp({w3[0], w3[1], w3[2]});
+  std::memcpy(R9, R.a, 72);
+  const sfmx_host::V3 l = sfmx_host::so3_log(R);
+  log3[0] = l.x; log3[1] = l.y; log3[2] = l.z;
+}
+double sfmx_host_hypot(double x, double y) { return sfmx::hypot_glibc(x, y); }
+
+}  // extern "C"

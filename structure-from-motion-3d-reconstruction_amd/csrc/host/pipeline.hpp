@@ -1,0 +1,176 @@
+// pipeline.hpp — C++20 host side of the SfM hot path: the reference's function seams
+// (KLTTracker::step, shi_tomasi, find_E_ransac, bundle_adjust_window) re-hosted on
+// the sfmx C ABI, plus the per-frame loop of main() (T:1686-1911) and its CSV/PLY writers.
+// Nothing here falls back to CPU arithmetic for the hot kernels: a failing C-ABI call is an error.
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../../include/sfmx.h"
+#include "host_math.hpp"
+
+namespace sfmx_host {
+
+struct SfmxFailure : std::runtime_error {
+  int status;
+  SfmxFailure(int st, const std::string& what) : std::runtime_error(what), status(st) {}
+};
+
+// T:307-316
+struct LKConfig {
+  int max_tracks = 2200, min_tracks = 900;
+  double quality = 0.01;
+  int min_distance = 8, pyr_levels = 3, win_radius = 5, iters = 10;
+  double fb_thresh = 1.0;
+};
+// T:811-817
+struct BAConfig {
+  int window = 6, iters = 5, max_points = 600;
+  double huber_delta = 3.0, lambda = 1e-3;
+};
+struct Track { int id; V2 p; };
+struct StepOut { std::vector<V2> prev_pts, cur_pts; std::vector<int> ids; };
+
+// where frames come from: host pixels, or pixels already resident in HBM
+struct FrameSource {
+  virtual ~FrameSource() = default;
+  virtual int count() const = 0;
+  virtual int width() const = 0;
+  virtual int height() const = 0;
+  // loads frame fi into pyr (level 0 + downsampled levels); throws std::runtime_error like read_pgm
+  virtual void load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) = 0;
+};
+struct MemoryFrames : FrameSource {
+  const std::uint8_t* host = nullptr;  // [n][h][w]
+  const std::uint8_t* dev = nullptr;   // same layout in HBM (preferred when non-null)
+  int n = 0, w = 0, h = 0;
+  int count() const override { return n; }
+  int width() const override { return w; }
+  int height() const override { return h; }
+  void load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) override;
+};
+
+struct StageClock {
+  double klt = 0, shi = 0, ransac = 0, ba = 0, upload = 0, host = 0, total = 0;
+  double klt_kernel_us = 0, ransac_kernel_us = 0, ba_kernel_us = 0, shi_kernel_us = 0;
+  std::uint64_t lk_steps = 0, tracks_in = 0, ransac_calls = 0, ransac_points = 0, ba_calls = 0, ba_iters = 0, klt_calls = 0;
+  std::uint64_t ransac_verified = 0;
+};
+
+// KLTTracker (T:323-466) on the GPU
+class GpuTracker {
+ public:
+  GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk);
+  ~GpuTracker();
+  GpuTracker(const GpuTracker&) = delete;
+  GpuTracker& operator=(const GpuTracker&) = delete;
+  StepOut step(FrameSource& src, int fi);
+  const std::vector<Track>& tracks() const { return tracks_; }
+  sfmx_pyramid* current() const { return prev_; }  // pyramid of the most recent frame
+  const LKConfig& cfg() const { return cfg_; }
+  // shi_tomasi (T:237-302): device score + ordered candidate compaction, host sort + greedy pick
+  std::vector<V2> shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist);
+  // fwd/bwd track of arbitrary points between two pyramids (loop-closure verification, T:1847-1854)
+  void track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd, std::vector<std::uint8_t>& keep);
+  int levels_total() const { return levels_total_; }
+
+ private:
+  void reset(FrameSource& src, int fi);
+  sfmx_ctx* ctx_;
+  LKConfig cfg_;
+  int w_, h_, levels_total_;
+  sfmx_pyramid* prev_ = nullptr;
+  sfmx_pyramid* cur_ = nullptr;
+  bool have_prev_ = false;
+  std::vector<Track> tracks_;
+  int next_id_ = 0;
+  StageClock* clk_;
+  std::vector<std::uint32_t> cand_xy_;
+  std::vector<double> cand_s_;
+};
+
+struct RelPose {
+  Mat3 R_ji;
+  V3 t_ji;
+  std::vector<int> inliers;
+  int best_iter = -1;
+};
+// find_E_ransac (T:646-761); throws std::runtime_error("Singular K") like the reference
+std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
+                                         double thr, int min_inliers, StageClock* clk);
+
+// T:766-798
+struct Keyframe {
+  int kf_id = 0, frame_idx = 0;
+  std::string img_name;
+  Pose pose;
+  std::unordered_map<int, V2> obs;
+};
+struct MapPoint {
+  int pid = 0, tid = 0;
+  V3 Xw;
+  std::vector<std::pair<int, V2>> obs;
+};
+struct MapState {
+  int next_pid = 0;
+  std::unordered_map<int, int> tid2pid;
+  std::unordered_map<int, MapPoint> pts;
+  bool has(int tid) const { return tid2pid.find(tid) != tid2pid.end(); }
+  int add(int tid, V3 Xw);
+  void add_obs(int tid, int kf_id, V2 uv);
+};
+struct PGEdge {
+  int i = -1, j = -1;
+  Mat3 R_ji;
+  V3 t_ji;
+  int inliers = 0;
+  bool is_loop = false;
+};
+
+// bundle_adjust_window (T:848-1097): S,b build + solve on the device, SO(3) update on the host
+class GpuBundleAdjuster {
+ public:
+  GpuBundleAdjuster(sfmx_ctx* ctx, StageClock* clk) : ctx_(ctx), clk_(clk) {}
+  ~GpuBundleAdjuster();
+  void run(const Mat3& K, std::vector<Keyframe>& kfs, MapState& map, const BAConfig& cfg);
+
+ private:
+  sfmx_ctx* ctx_;
+  StageClock* clk_;
+  sfmx_ba_problem* prob_ = nullptr;
+};
+
+bool posegraph_optimize_centers(sfmx_ctx* ctx, std::vector<Keyframe>& kfs, const std::vector<PGEdge>& edges);
+
+struct PipelineConfig {
+  int frames = 12;
+  bool export_pointcloud = true;
+  LKConfig klt;
+  BAConfig ba;
+  int kf_min_gap = 1, kf_min_inliers = 200;
+  double kf_parallax_px = 18.0;
+};
+struct FrameMeta {
+  std::string name;
+  double lat = 0, lon = 0;
+  bool has_ang = false;
+};
+struct PipelineResult {
+  std::vector<Keyframe> kfs;
+  std::vector<PGEdge> edges;
+  MapState map;
+  std::string log;  // exactly what the reference prints to stdout
+  StageClock clock;
+};
+// The per-frame loop of main() (T:1708-1871).  `echo` (optional) receives each stdout line as it is produced.
+void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>& meta, const Mat3& K, const PipelineConfig& cfg,
+                  PipelineResult& out, void (*echo)(const std::string&) = nullptr);
+// writers (T:1199-1224, 1463-1475) + the summary block (T:1908-1911); appends the summary to out.log
+void write_outputs(const std::string& out_dir, const PipelineConfig& cfg, const std::vector<FrameMeta>& meta, PipelineResult& out);
+
+}  // namespace sfmx_host

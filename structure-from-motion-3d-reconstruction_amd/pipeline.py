@@ -1,0 +1,85 @@
+"""ctypes binding of the C++ host pipeline (libsfmx_host.so: sfmx_pipeline_run) — plumbing only."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_ubyte, c_ulonglong, c_void_p
+
+import numpy as np
+
+from . import capi
+
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libsfmx_host.so")
+CLI_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "templering_sfm")
+
+
+class PipelineCfg(ctypes.Structure):
+    _fields_ = [("frames", c_int), ("export_pointcloud", c_int), ("max_tracks", c_int), ("min_tracks", c_int),
+                ("quality", c_double), ("min_distance", c_int), ("pyr_levels", c_int), ("win_radius", c_int),
+                ("klt_iters", c_int), ("fb_thresh", c_double), ("kf_min_gap", c_int), ("kf_min_inliers", c_int),
+                ("kf_parallax_px", c_double), ("ba_window", c_int), ("ba_iters", c_int), ("ba_max_points", c_int),
+                ("ba_huber", c_double), ("ba_lambda", c_double)]
+
+
+class PipelineStats(ctypes.Structure):
+    _fields_ = [("n_keyframes", c_int), ("n_points", c_int), ("n_edges", c_int), ("n_frames", c_int),
+                ("sec_total", c_double), ("sec_klt", c_double), ("sec_shi", c_double), ("sec_ransac", c_double),
+                ("sec_ba", c_double), ("sec_upload", c_double), ("sec_host", c_double),
+                ("us_klt_kernel", c_double), ("us_ransac_kernel", c_double), ("us_ba_kernel", c_double),
+                ("us_shi_kernel", c_double),
+                ("lk_steps", c_ulonglong), ("tracks_in", c_ulonglong), ("klt_calls", c_ulonglong),
+                ("ransac_calls", c_ulonglong), ("ransac_points", c_ulonglong), ("ba_calls", c_ulonglong),
+                ("ba_iters", c_ulonglong), ("ransac_verified", c_ulonglong)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+DEFAULTS = dict(frames=12, export_pointcloud=1, max_tracks=2200, min_tracks=900, quality=0.01, min_distance=8,
+                pyr_levels=3, win_radius=5, klt_iters=10, fb_thresh=1.0, kf_min_gap=1, kf_min_inliers=200,
+                kf_parallax_px=18.0, ba_window=6, ba_iters=5, ba_max_points=600, ba_huber=3.0, ba_lambda=1e-3)
+
+_host = None
+
+
+def load_host_library() -> ctypes.CDLL:
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise capi.SfmxError(capi.SFMX_ERR_NO_DEVICE, f"{HOST_LIB_PATH} not built: run __graft_entry__.build()")
+        capi.load_library()
+        _host = ctypes.CDLL(HOST_LIB_PATH)
+        _host.sfmx_host_hypot.restype = c_double
+        _host.sfmx_host_hypot.argtypes = [c_double, c_double]
+    return _host
+
+
+def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=None, cfg: dict | None = None,
+        out_dir: str | None = None, images_dev: int | None = None, shape=None, timing: bool = False):
+    """Run the per-frame loop.  images: host [F,h,w] u8, or images_dev: device pointer with shape=(F,h,w)."""
+    lib = load_host_library()
+    if images is not None:
+        images = np.ascontiguousarray(images, np.uint8)
+        F, h, w = images.shape
+    else:
+        F, h, w = shape
+    c = PipelineCfg(**{**DEFAULTS, **(cfg or {})})
+    arr = (c_char_p * F)(*[str(n).encode() for n in names])
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    lat = np.zeros(F) if lat is None else np.ascontiguousarray(lat, np.float64)
+    lon = np.zeros(F) if lon is None else np.ascontiguousarray(lon, np.float64)
+    has_ang = np.ones(F, np.uint8)
+    log = ctypes.create_string_buffer(1 << 20)
+    st = PipelineStats()
+    centres = np.zeros((F, 3))
+    ctx.set_timing(timing)
+    rc = lib.sfmx_pipeline_run(ctx.h_, images.ctypes.data_as(c_void_p) if images is not None else None,
+                               c_void_p(images_dev) if images_dev else None, c_int(F), c_int(w), c_int(h), arr,
+                               K.ctypes.data_as(POINTER(c_double)), lat.ctypes.data_as(POINTER(c_double)),
+                               lon.ctypes.data_as(POINTER(c_double)), has_ang.ctypes.data_as(POINTER(c_ubyte)), byref(c),
+                               out_dir.encode() if out_dir else None, log, c_int(len(log)), byref(st),
+                               centres.ctypes.data_as(POINTER(c_double)), c_int(F))
+    text = log.value.decode()
+    if rc != capi.SFMX_OK:
+        raise capi.SfmxError(rc, text.strip())
+    return dict(log=text, stats=st.asdict(), centres=centres[:st.n_keyframes].copy())

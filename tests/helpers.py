@@ -114,11 +114,15 @@ def bits(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-def assert_bits_equal(a, b, what=""):
+def assert_bits_equal(a, b, what="", nan_equal=False):
+    """nan_equal: any NaN matches any NaN (x86 generates the negative 'indefinite' QNaN, gfx950 the
+    positive canonical one; NaN-ness is part of the parity contract, its sign/payload is not)."""
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     ne = a.view(np.uint64) != b.view(np.uint64)
+    if nan_equal:
+        ne &= ~(np.isnan(a) & np.isnan(b))
     if ne.any():
         idx = np.argwhere(ne)[:5]
         raise AssertionError(

@@ -257,4 +257,4 @@ def test_solve_dense(ctx, golden):
     rc, x = ctx.solve_dense(A, np.ones(9))
     erc, ex = H.solve_gauss(O, "orc", A, np.ones(9))
     assert rc == erc == 0
-    H.assert_bits_equal(x, ex, "nan solve")
+    H.assert_bits_equal(x, ex, "nan solve", nan_equal=True)

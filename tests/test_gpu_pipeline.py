@@ -1,0 +1,107 @@
+"""GPU suite: the whole per-frame loop (C++ host pipeline on the sfmx C ABI) and the drop-in CLI.
+
+Two comparators:
+ * the golden output of the REAL reference CLI for everything the reference computes with defined
+   behaviour (stdout, posegraph_edges.csv, keyframe selection) -- see check_e2e_against_reference;
+ * the oracle's pipeline (same Q12 reading) for every byte of every output file, including the map
+   points and BA-refined camera centres."""
+import importlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_oracle_golden import check_e2e_against_reference
+
+pytestmark = pytest.mark.gpu
+capi = importlib.import_module(H.PKG_NAME + ".capi")
+pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+synth = importlib.import_module(H.PKG_NAME + ".synth")
+FILES = ("keyframes_camera_centers.csv", "posegraph_edges.csv", "templeRing_sparse_points.ply")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _same_files(a, b):
+    for fn in FILES:
+        ta, tb = open(os.path.join(a, fn)).read(), open(os.path.join(b, fn)).read()
+        assert ta == tb, f"{fn} differs:\n{ta[:400]}\n---\n{tb[:400]}"
+
+
+@pytest.mark.parametrize("name", ["e2e_small", "e2e_keyframes"])
+def test_pipeline_matches_reference_and_oracle(ctx, name, tmp_path):
+    g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+    cfg = H.pipe_cfg_from_json(json.loads(str(g["config"])))
+    names = [str(s) for s in g["names"]]
+    out_g, out_o = str(tmp_path / "gpu"), str(tmp_path / "orc")
+    r = pipe.run(ctx, g["images"], names, g["K"], g["lat"], g["lon"], cfg, out_g)
+    check_e2e_against_reference(g, r["log"], out_g)
+    rc, olog, nk, npnt = H.orc_pipeline_run(g["images"], names, g["K"], g["lat"], g["lon"], cfg, out_o)
+    assert rc == 0
+    assert r["log"].replace(out_g, "X") == olog.replace(out_o, "X")
+    _same_files(out_g, out_o)
+    assert r["stats"]["n_keyframes"] == nk and r["stats"]["n_points"] == npnt
+
+
+def test_pipeline_640x480_vs_oracle(ctx, tmp_path):
+    """Full-size frames, default reference config, BA + keyframes firing; every output byte vs the oracle."""
+    seq = synth.make_sequence(6, 640, 480, 0.3, n_blobs=20000, seed=7)
+    cfg = dict(H.PIPE_DEFAULTS, frames=6)
+    out_g, out_o = str(tmp_path / "gpu"), str(tmp_path / "orc")
+    r = pipe.run(ctx, seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out_g)
+    rc, olog, nk, npnt = H.orc_pipeline_run(seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out_o)
+    assert rc == 0 and nk >= 3 and npnt > 100
+    assert r["log"].replace(out_g, "X") == olog.replace(out_o, "X")
+    _same_files(out_g, out_o)
+
+
+def test_device_resident_frames_give_identical_results(ctx, tmp_path):
+    import torch
+    g = np.load(os.path.join(H.GOLDEN, "e2e_keyframes.npz"))
+    cfg = H.pipe_cfg_from_json(json.loads(str(g["config"])))
+    names = [str(s) for s in g["names"]]
+    a, b = str(tmp_path / "host"), str(tmp_path / "dev")
+    r1 = pipe.run(ctx, g["images"], names, g["K"], g["lat"], g["lon"], cfg, a)
+    dev = torch.from_numpy(np.ascontiguousarray(g["images"])).to("cuda:0")
+    torch.cuda.synchronize()
+    r2 = pipe.run(ctx, None, names, g["K"], g["lat"], g["lon"], cfg, b, images_dev=dev.data_ptr(), shape=tuple(dev.shape))
+    assert r1["log"].replace(a, "X") == r2["log"].replace(b, "X")
+    _same_files(a, b)
+
+
+def test_cli_drop_in(tmp_path):
+    """The templering_sfm binary on a dataset directory: same stdout / files as the oracle, same exit codes."""
+    g = np.load(os.path.join(H.GOLDEN, "e2e_small.npz"))
+    cfgj = json.loads(str(g["config"]))
+    names = [str(s) for s in g["names"]]
+    root = str(tmp_path / "data")
+    seq = dict(images=g["images"], K=g["K"], R=g["R"], t=g["t"], names=names, lat=g["lat"], lon=g["lon"])
+    synth.write_dataset(root, seq)
+    with open(os.path.join(root, "cfg.json"), "w") as f:
+        json.dump(cfgj, f)
+    out = os.path.join(root, "out")
+    p = subprocess.run([pipe.CLI_PATH, root, out, "--config", os.path.join(root, "cfg.json")], capture_output=True, text=True, cwd=root)
+    assert p.returncode == 0, p.stderr
+    check_e2e_against_reference(g, p.stdout.replace(out, "<OUT>").replace("<OUT>", out), out)
+    out_o = str(tmp_path / "orc")
+    rc, olog, _, _ = H.orc_pipeline_run(g["images"], names, g["K"], g["lat"], g["lon"], H.pipe_cfg_from_json(cfgj), out_o)
+    assert p.stdout.replace(out, "X") == olog.replace(out_o, "X")
+    _same_files(out, out_o)
+    # exit codes / messages of the reference CLI (T:1520-1536, 1605-1611, 1913-1916)
+    assert subprocess.run([pipe.CLI_PATH], capture_output=True).returncode == 2
+    q = subprocess.run([pipe.CLI_PATH, root, out, "--help"], capture_output=True, text=True)
+    assert q.returncode == 0 and "Run without args to see usage." in q.stderr
+    q = subprocess.run([pipe.CLI_PATH, root, out, "--bogus"], capture_output=True, text=True)
+    assert q.returncode == 1 and q.stderr.strip() == "ERROR: Unknown option: --bogus"
+    q = subprocess.run([pipe.CLI_PATH, str(tmp_path / "nope"), out], capture_output=True, text=True, cwd=str(tmp_path))
+    assert q.returncode == 1 and q.stderr.startswith("ERROR: Failed to open: ")
+    q = subprocess.run([pipe.CLI_PATH, root, out, "3", "--export-geometry", "none"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert q.returncode == 0 and q.stdout.count("frame ") == 3

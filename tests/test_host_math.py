@@ -1,0 +1,72 @@
+"""CPU suite: the product's host-side math (libsfmx_host.so; libm-dependent pieces that stay on the
+host by design) against the golden vectors from the reference build.  No device calls."""
+import ctypes
+import importlib
+
+import numpy as np
+
+import helpers as H
+
+pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+L = H.CLib(pipe.HOST_LIB_PATH)
+
+
+def test_host_rng_matches_libstdcxx(golden):
+    for n in (8, 100, 517, 5000, 3):
+        out = np.zeros(4096, np.int32)
+        L.call("sfmx_host_uniform_draws", None, ctypes.c_uint(12345), n, 4096, out)
+        assert np.array_equal(out, golden[f"rng_{n}"])
+
+
+def test_host_eight_point_is_reference_exact(golden):
+    xi, xj = golden["tv_xi"], golden["tv_xj"]
+    for k, idx in enumerate(golden["tv_idx8"]):
+        E = np.zeros((3, 3))
+        L.call("sfmx_host_eight_point_E", None, H.f64(xi), H.f64(xj), H.i32(idx), E)
+        H.assert_bits_equal(E, golden["tv_E"][k], f"E[{k}]")
+
+
+def test_host_decompose_matches_find_E_ransac(golden):
+    """winner E (oracle diagnostic, itself pinned to the reference) -> R,t must equal the reference's RelPose"""
+    O = H.oracle()
+    for iters, thr, mi in golden["rs_cases"]:
+        tag = f"{int(iters)}_{int(mi)}"
+        if not int(golden[f"rs_ok_{tag}"][0]):
+            continue
+        r = H.find_E_ransac(O, "orc", golden["tv_K"], golden["tv_pi"], golden["tv_pj"], int(iters), float(thr), int(mi))
+        R, t = np.zeros((3, 3)), np.zeros(3)
+        inl = H.i32(golden[f"rs_inl_{tag}"])
+        L.call("sfmx_host_decompose_E", None, H.f64(r["E"]), H.f64(golden["tv_xi"]), H.f64(golden["tv_xj"]), inl, len(inl), R, t)
+        H.assert_bits_equal(R, golden[f"rs_R_{tag}"], "R")
+        H.assert_bits_equal(t, golden[f"rs_t_{tag}"], "t")
+
+
+def test_host_triangulate_and_so3(golden):
+    K = golden["tv_K"]
+    for k, row in enumerate(golden["tri_in"]):
+        X = np.zeros(3)
+        L.call("sfmx_host_triangulate_dlt", None, H.f64(K).reshape(9), H.f64(row[0:9]), H.f64(row[9:12]), H.f64(row[12:21]),
+               H.f64(row[21:24]), H.f64(row[24:26]), H.f64(row[26:28]), X)
+        H.assert_bits_equal(X, golden["tri_out"][k], f"tri {k}")
+    for k, w in enumerate(golden["so3_w"]):
+        R, lg = np.zeros((3, 3)), np.zeros(3)
+        L.call("sfmx_host_so3", None, H.f64(w), R, lg)
+        H.assert_bits_equal(R, golden["so3_R"][k], "exp")
+        H.assert_bits_equal(lg, golden["so3_log"][k], "log")
+
+
+def test_hypot_restatement_matches_libm():
+    """sfmx_math.h hypot_glibc (the function the device kernels use) vs the platform libm."""
+    rng = np.random.default_rng(2)
+    x = np.ldexp(rng.uniform(-1, 1, 200000), rng.integers(-40, 40, 200000))
+    y = np.ldexp(rng.uniform(-1, 1, 200000), rng.integers(-40, 40, 200000))
+    y[::5] = x[::5] * rng.uniform(-1, 1, x[::5].size)
+    x[:1000] *= 1e-3
+    fn = L.dll.sfmx_host_hypot
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_double, ctypes.c_double]
+    got = np.array([fn(float(a), float(b)) for a, b in zip(x[:60000], y[:60000])])
+    H.assert_bits_equal(got, np.hypot(x[:60000], y[:60000]), "hypot")
+    for a, b in [(0.0, 0.0), (np.inf, 1.0), (3.0, 0.0), (0.0, -4.0), (1e300, 1e300), (1e-320, 1e-320), (5e-324, 0.0)]:
+        assert fn(a, b) == np.hypot(a, b)
+    assert np.isnan(fn(float("nan"), 1.0))
