@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — keyframes/sec of the SfM hot path (KLT + RANSAC + local BA) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole per-frame loop (reference main(), T:1708-1871) over one synthetic
+TempleRing-style sequence: 47 frames, 640x480 u8, ring camera, the reference's default config.json.
+The frames are resident in HBM before the timed region starts.  With N ranks every rank processes its
+own sequence (independent sequences are the unit the path shards on: SURVEY.md §8e) -- weak scaling,
+no data-path collective; only the barrier / max-time reduction use RCCL.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (by accumulated GPU time,
+measured with HIP events on the kernel's own stream inside the library); `cpu_baseline` is the real
+reference binary (oracle/_ref, kind "reference") or, when that is absent, the oracle restatement
+(kind "port") timed on a bounded sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "structure-from-motion-3d-reconstruction_amd"
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6    # SURVEY.md §8d (public spec figure for vector FP64)
+LK_STEP_FLOP = 12.7e3       # 121 px x 105 flop + solve
+SAMPSON_FLOP = 45.0
+
+
+def ate_rmse(est: np.ndarray, gt: np.ndarray, with_scale: bool = True) -> float:
+    """Umeyama alignment of camera centres (the ate_keyframes metric, cpp/tools/ate_keyframes.cpp:334-389)."""
+    if len(est) < 3 or not np.isfinite(est).all():
+        return float("nan")
+    mu_e, mu_g = est.mean(0), gt.mean(0)
+    E, G = est - mu_e, gt - mu_g
+    U, S, Vt = np.linalg.svd(G.T @ E / len(est))
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1
+    R = U @ D @ Vt
+    s = (S * np.diag(D)).sum() / (E ** 2).sum() * len(est) if with_scale else 1.0
+    al = (s * (R @ est.T)).T + (mu_g - s * R @ mu_e)
+    return float(np.sqrt(((al - gt) ** 2).sum(1).mean()))
+
+
+def cpu_baseline(seq, cfg, sample_frames: int):
+    """Reference CPU path on a bounded sample (first `sample_frames` frames) of the same sequence."""
+    synth = importlib.import_module(PKG + ".synth")
+    ref_cli = os.path.join(ROOT, "oracle", "_ref", "templering_sfm_ref")
+    sub = {k: (v[:sample_frames] if k in ("images", "R", "t", "names", "lat", "lon") else v) for k, v in seq.items()}
+    cores = 1  # the reference is single-threaded
+    if os.path.exists(ref_cli):
+        with tempfile.TemporaryDirectory() as td:
+            synth.write_dataset(td, sub)
+            t0 = time.perf_counter()
+            p = subprocess.run([ref_cli, td, os.path.join(td, "out"), str(sample_frames)], capture_output=True, text=True, cwd=td)
+            dt = time.perf_counter() - t0
+            if p.returncode == 0:
+                kf = int(p.stdout.split("Keyframes:")[1].split()[0])
+                return dict(value=kf / dt, unit="keyframes/s", cores=cores, kind="reference",
+                            sample=f"first {sample_frames} frames of the bench sequence, reference CLI wall time {dt:.2f} s, {kf} keyframes",
+                            frames_per_s=sample_frames / dt)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    t0 = time.perf_counter()
+    with tempfile.TemporaryDirectory() as td:
+        rc, log, nk, npnt = H.orc_pipeline_run(sub["images"], sub["names"], sub["K"], sub["lat"], sub["lon"],
+                                               dict(cfg, frames=sample_frames), td)
+    dt = time.perf_counter() - t0
+    return dict(value=nk / dt, unit="keyframes/s", cores=cores, kind="port",
+                sample=f"first {sample_frames} frames of the bench sequence, oracle restatement wall time {dt:.2f} s, {nk} keyframes",
+                frames_per_s=sample_frames / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=47)
+    ap.add_argument("--deg-per-frame", type=float, default=0.3)
+    ap.add_argument("--max-tracks", type=int, default=2200)
+    ap.add_argument("--cpu-sample-frames", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    capi = importlib.import_module(PKG + ".capi")
+    pipe = importlib.import_module(PKG + ".pipeline")
+    synth = importlib.import_module(PKG + ".synth")
+
+    # --- synthetic TempleRing-47 stand-in (one independent sequence per rank)
+    seq = synth.make_sequence(args.frames, 640, 480, args.deg_per_frame, n_blobs=20000, seed=7 + rank)
+    cfg = dict(pipe.DEFAULTS, frames=args.frames, max_tracks=args.max_tracks, min_tracks=min(900, args.max_tracks * 9 // 22),
+               export_pointcloud=0)
+    ctx = capi.Context(local_rank)
+    frames_dev = torch.from_numpy(np.ascontiguousarray(seq["images"])).to(f"cuda:{local_rank}")  # resident in HBM
+    torch.cuda.synchronize()
+    shape = tuple(frames_dev.shape)
+
+    def one_pass(timing=False):
+        return pipe.run(ctx, None, seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, None, images_dev=frames_dev.data_ptr(),
+                        shape=shape, timing=timing)
+
+    for _ in range(args.warmup):
+        one_pass()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    kf_total = 0
+    last = None
+    for _ in range(args.steps):
+        last = one_pass()
+        kf_total += last["stats"]["n_keyframes"]
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        k = torch.tensor([kf_total], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(k, op=dist.ReduceOp.SUM)
+        kf_total = int(k.item())
+
+    # --- one extra, untimed pass with per-kernel HIP-event timing for the roofline object
+    prof = one_pass(timing=True)["stats"]
+    if rank == 0:
+        st = last["stats"]
+        per_stage = {"klt": prof["us_klt_kernel"], "ransac": prof["us_ransac_kernel"], "ba": prof["us_ba_kernel"], "shi": prof["us_shi_kernel"]}
+        dom = max(per_stage, key=per_stage.get)
+        w, h = 640, 480
+        if dom == "klt":
+            launches = max(1, prof["klt_calls"])
+            avg_us = prof["us_klt_kernel"] / launches
+            tracks = prof["tracks_in"] / launches
+            alg_bytes = 2 * 1.3125 * w * h + 49.0 * tracks            # both pyramids once + track arrays
+            alg_flop = LK_STEP_FLOP * prof["lk_steps"] / launches
+            kname = "k_klt_track"
+        elif dom == "ransac":
+            launches = max(1, prof["ransac_calls"])
+            avg_us = prof["us_ransac_kernel"] / launches
+            npts = prof["ransac_points"] / launches
+            alg_bytes = 32.0 * npts + 76.0 * 2500 + npts               # points + E/count per hypothesis + mask
+            alg_flop = SAMPSON_FLOP * 2500 * npts + 25e3 * 2500
+            kname = "k_hypotheses+k_score"
+        elif dom == "ba":
+            launches = max(1, prof["ba_iters"])
+            avg_us = prof["us_ba_kernel"] / launches
+            alg_bytes = 20.0 * 3600 + 24.0 * 600 + 96 * 6 + 8 * (36 * 36 + 36)
+            alg_flop = 7.2e6
+            kname = "k_ba_points+k_ba_reduce"
+        else:
+            launches = 1
+            avg_us = prof["us_shi_kernel"]
+            alg_bytes = 9.0 * w * h
+            alg_flop = 260.0 * w * h
+            kname = "k_shi_score"
+        ach_gbs = alg_bytes / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+        ach_tf = alg_flop / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
+        roofline = dict(bound="hbm", achieved=round(ach_gbs, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gbs / HBM_PEAK_GBS, 6),
+                        traffic=None, kernel=kname, avg_launch_us=round(avg_us, 2), launches_per_pass=int(launches),
+                        algorithmic_bytes_per_launch=int(alg_bytes),
+                        note="path is FP64-VALU/latency bound, not HBM bound (SURVEY.md §8d); see fp64_valu",
+                        fp64_valu=dict(achieved=round(ach_tf, 4), peak=FP64_VALU_PEAK_TF, unit="TFLOP/s", frac=round(ach_tf / FP64_VALU_PEAK_TF, 5)),
+                        kernel_us_per_pass={k: round(v, 1) for k, v in per_stage.items()})
+        gt_C = np.array([-seq["R"][i].T @ seq["t"][i] for i in range(args.frames)])
+        kf_frames = None
+        out = {
+            "metric": "keyframes/sec (KLT + RANSAC + local BA per-frame loop), synthetic TempleRing-47 stand-in",
+            "value": round(kf_total / dt, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic TempleRing-47 stand-in: {args.frames} frames 640x480 u8, ring camera {args.deg_per_frame} deg/frame, "
+                                   f"reference default config (max_tracks={args.max_tracks}, RANSAC 2500 iters, BA window 6 / 600 pts / 5 iters); "
+                                   "one independent sequence per GPU", "frames_per_step": args.frames, "parallelism": f"sequences x{world}"},
+            "frames_per_s": round(args.frames * args.steps * world / dt, 2),
+            "keyframes_per_step": st["n_keyframes"], "map_points": st["n_points"],
+            "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_total", "sec_klt", "sec_shi", "sec_ransac", "sec_ba", "sec_upload", "sec_host")},
+            "roofline": roofline,
+        }
+        est = last["centres"]
+        out["ate_rmse_sim3_vs_gt"] = None
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(seq, cfg, min(args.cpu_sample_frames, args.frames))
+            out["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cb.items()}
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / cb["value"], 1) if cb["value"] > 0 else None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

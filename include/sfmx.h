@@ -93,7 +93,8 @@ int sfmx_ransac_score(sfmx_ctx* ctx, const double* xi, const double* xj, int n, 
                       int H, double thr, int32_t* counts_out, int32_t* best_iter, int32_t* best_count,
                       double* E_out);
 /* inlier mask of ONE essential matrix (used for the winner after the host has re-derived its E
- * with the platform libm, so the mask and E are bit-identical to the reference's) */
+ * with the platform libm, so the mask and E are bit-identical to the reference's).  Passing
+ * xi == xj == NULL reuses the n correspondences left in HBM by the preceding sfmx_ransac_score. */
 int sfmx_sampson_mask(sfmx_ctx* ctx, const double* xi, const double* xj, int n, const double* E9,
                       double thr, uint8_t* mask_out, int32_t* count_out);
 

@@ -463,6 +463,7 @@ int sfmx_solve_dense(sfmx_ctx* c, const double* A, const double* b, int n, doubl
   SFMX_REQUIRE(c, c && A && b && x && n >= 1);
   if (n > SOLVE_MAX_N) return sfmx_fail(c, SFMX_ERR_UNSUPPORTED, "sfmx_solve_dense: n > 4096 (single-workgroup solver)", hipSuccess);
   const size_t nb = (size_t)n * n * 8;
+  c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(nb));
   SFMX_HIP(c, c->d[1].ensure((size_t)n * 8));
   SFMX_HIP(c, c->d[2].ensure((size_t)n * 8 + 64));

@@ -78,6 +78,7 @@ extern "C" {
 int sfmx_debug_hypot(sfmx_ctx* c, const double* x, const double* y, int n, double* out) {
   SFMX_REQUIRE(c, c && x && y && out && n > 0);
   const size_t nb = (size_t)n * 8;
+  c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(nb));
   SFMX_HIP(c, c->d[1].ensure(nb));
   SFMX_HIP(c, c->d[2].ensure(nb));

@@ -243,6 +243,7 @@ extern "C" {
 int sfmx_shi_tomasi_score(sfmx_ctx* c, const sfmx_pyramid* p, double* score_out, double* max_out) {
   SFMX_REQUIRE(c, c && p && (score_out || max_out));
   const size_t n = (size_t)p->w * p->h;
+  c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(n * 8));
   SFMX_HIP(c, c->d[1].ensure(64));
   int rc = launch_score(c, p, c->d[0].as<double>(), c->d[1].as<unsigned long long>());
@@ -260,6 +261,7 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
                                double* cand_score, int* n_out, double* max_out) {
   SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 65536 && p->h < 65536);
   const size_t n = (size_t)p->w * p->h;
+  c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(n * 8));
   SFMX_HIP(c, c->d[1].ensure(64));
   SFMX_HIP(c, c->d[2].ensure((size_t)(p->h + 1) * 4 + 64));

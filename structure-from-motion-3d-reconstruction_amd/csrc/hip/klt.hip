@@ -186,6 +186,7 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   if (n == 0) return SFMX_OK;
   SFMX_REQUIRE(c, xy_in != nullptr);
   const size_t nb = (size_t)n * 16;
+  c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(nb));       // xy_in
   SFMX_HIP(c, c->d[1].ensure(nb));       // fwd
   SFMX_HIP(c, c->d[2].ensure(nb));       // back

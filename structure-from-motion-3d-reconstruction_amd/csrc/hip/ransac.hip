@@ -358,10 +358,11 @@ int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, co
   SFMX_HIP(c, c->d[2].ensure((size_t)H * 32));
   SFMX_HIP(c, c->d[3].ensure((size_t)H * 72));
   SFMX_HIP(c, c->d[4].ensure((size_t)H * 4 + 64));
-  SFMX_HIP(c, c->d[5].ensure(64));
+  SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
   SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xi, pb, hipMemcpyHostToDevice, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(c->d[2].p, idx8, (size_t)H * 32, hipMemcpyHostToDevice, c->stream));
+  c->resident_points = n;
   KernelTimer t(c);
   t.start();
   k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[2].as<int32_t>(), H, 120,
@@ -382,26 +383,30 @@ int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, co
   return SFMX_OK;
 }
 
-// xi/xj are expected to be the arrays of the preceding sfmx_ransac_score call most of the time, but
-// the entry point is self-contained: it uploads them again (n*32 bytes).
+// xi == xj == NULL reuses the correspondences left in HBM by the preceding sfmx_ransac_score call
+// (n must match); otherwise they are uploaded (n*32 bytes).
 int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, const double* E9, double thr, uint8_t* mask_out,
                       int32_t* count_out) {
-  SFMX_REQUIRE(c, c && xi && xj && E9 && mask_out && n > 0);
+  SFMX_REQUIRE(c, c && E9 && mask_out && n > 0 && ((xi && xj) || (!xi && !xj && c->resident_points == n)));
   const size_t pb = (size_t)n * 16;
-  SFMX_HIP(c, c->d[0].ensure(pb));
-  SFMX_HIP(c, c->d[1].ensure(pb));
   SFMX_HIP(c, c->d[6].ensure(128));
-  SFMX_HIP(c, c->d[7].ensure((size_t)n + 64));
-  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xi, pb, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
+  if (xi) {
+    SFMX_HIP(c, c->d[0].ensure(pb));
+    SFMX_HIP(c, c->d[1].ensure(pb));
+    SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xi, pb, hipMemcpyHostToDevice, c->stream));
+    SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
+    c->resident_points = n;
+  }
   SFMX_HIP(c, hipMemcpyAsync(c->d[6].p, E9, 72, hipMemcpyHostToDevice, c->stream));
   int32_t* d_cnt = reinterpret_cast<int32_t*>(c->d[6].as<char>() + 96);
   SFMX_HIP(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+  uint8_t* d_mask = c->d[5].as<uint8_t>() + 64;  // d[5][0..7] holds the argmax pair of ransac_score
   k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[6].as<double>(), thr,
-                                                       c->d[7].as<uint8_t>(), d_cnt);
+                                                       d_mask, d_cnt);
   SFMX_HIP(c, hipGetLastError());
   int32_t cnt = 0;
-  SFMX_HIP(c, hipMemcpyAsync(mask_out, c->d[7].p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(mask_out, d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   if (count_out) *count_out = cnt;

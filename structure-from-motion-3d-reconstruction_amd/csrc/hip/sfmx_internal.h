@@ -64,6 +64,7 @@ struct sfmx_ctx {
   // reusable staging: a few independent device / pinned slabs
   DevBuf d[8];
   PinBuf h[4];
+  int resident_points = 0;  // #correspondences left in d[0]/d[1] by the last RANSAC call
 };
 
 struct sfmx_pyramid {

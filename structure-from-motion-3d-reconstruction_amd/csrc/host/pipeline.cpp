@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -52,32 +53,76 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
   double maxv = 0;
   check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &n, &maxv), "shi_tomasi_candidates");
   if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
-  struct Cand { int x, y; double s; };
-  std::vector<Cand> cands((size_t)n);
-  for (int i = 0; i < n; i++) cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0xffffu), (int)(cand_xy_[(size_t)i] >> 16), cand_s_[(size_t)i]};
-  // same libstdc++ introsort, same input order, same predicate as T:286 => same permutation
-  std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s; });
-  // greedy min-distance pick (T:288-300).  "no accepted corner closer than min_dist" does not depend
-  // on the order in which accepted corners are visited, so a uniform grid replaces the O(N*K) scan.
-  std::vector<V2> out;
-  out.reserve((size_t)std::max(0, max_corners));
+  struct Cand { int x, y; double s; int idx; };
+  const double md2 = (double)min_dist * min_dist;
   const int cell = std::max(1, min_dist);
   const int gw = w / cell + 1, gh = h / cell + 1;
-  std::vector<std::vector<int>> grid((size_t)gw * gh);
-  const double md2 = (double)min_dist * min_dist;
-  for (const Cand& c : cands) {
-    bool ok = true;
-    const int cx = c.x / cell, cy = c.y / cell;
-    for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1) && ok; gy++)
-      for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1) && ok; gx++)
-        for (int idx : grid[(size_t)gy * gw + gx]) {
-          const double dx = out[(size_t)idx].x - c.x, dy = out[(size_t)idx].y - c.y;
-          if (dx * dx + dy * dy < md2) { ok = false; break; }
-        }
-    if (!ok) continue;
-    grid[(size_t)cy * gw + cx].push_back((int)out.size());
-    out.push_back(V2{double(c.x), double(c.y)});
-    if ((int)out.size() >= max_corners) break;
+  std::vector<int> head, next;
+  std::vector<V2> out;
+  // greedy min-distance pick (T:288-300) over cands[0..limit).  "no accepted corner closer than
+  // min_dist" does not depend on the order in which accepted corners are visited, so a uniform grid
+  // replaces the O(N*K) scan.  Returns the number of candidates consumed.
+  auto greedy = [&](const std::vector<Cand>& cands, size_t limit, bool& finished) -> size_t {
+    out.clear();
+    out.reserve((size_t)std::max(0, max_corners));
+    head.assign((size_t)gw * gh, -1);
+    next.clear();
+    finished = false;
+    size_t k = 0;
+    for (; k < limit; k++) {
+      const Cand& c = cands[k];
+      bool ok = true;
+      const int cx = c.x / cell, cy = c.y / cell;
+      for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1) && ok; gy++)
+        for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1) && ok; gx++)
+          for (int idx = head[(size_t)gy * gw + gx]; idx >= 0; idx = next[(size_t)idx]) {
+            const double dx = out[(size_t)idx].x - c.x, dy = out[(size_t)idx].y - c.y;
+            if (dx * dx + dy * dy < md2) { ok = false; break; }
+          }
+      if (!ok) continue;
+      next.push_back(head[(size_t)cy * gw + cx]);
+      head[(size_t)cy * gw + cx] = (int)out.size();
+      out.push_back(V2{double(c.x), double(c.y)});
+      if ((int)out.size() >= max_corners) { finished = true; k++; break; }
+    }
+    return k;
+  };
+  std::vector<Cand> cands((size_t)n);
+  auto fill = [&]() {
+    for (int i = 0; i < n; i++)
+      cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0xffffu), (int)(cand_xy_[(size_t)i] >> 16), cand_s_[(size_t)i], i};
+  };
+  fill();
+  // Fast path: only the best-scoring prefix is ever consumed.  Select and sort that prefix with the
+  // total order (score desc, row-major index asc).  If no two candidates of equal score occur in
+  // the consumed range (+1), every correct sort -- including the reference's std::sort at T:286 --
+  // orders that range identically, so the result is exact.  Equal scores => exact slow path below.
+  bool done = false;
+  static const bool force_full_sort = std::getenv("SFMX_SHI_FULL_SORT") != nullptr;  // test hook
+  if (!force_full_sort) {
+    auto total = [](const Cand& a, const Cand& b) { return a.s > b.s || (a.s == b.s && a.idx < b.idx); };
+    size_t K = std::min((size_t)n, (size_t)std::max(4096, 6 * std::max(1, max_corners)));
+    while (!done) {
+      if (K < (size_t)n) std::nth_element(cands.begin(), cands.begin() + (long)K, cands.end(), total);
+      std::sort(cands.begin(), cands.begin() + (long)K, total);
+      bool finished = false;
+      const size_t used = greedy(cands, K, finished);
+      if (!finished && K < (size_t)n) { K = std::min((size_t)n, K * 2); continue; }
+      if (finished && used == K && K < (size_t)n) { K = std::min((size_t)n, K * 2); continue; }  // need cands[used] for the tie test
+      bool tie = false;
+      const size_t lim = std::min(K, used + 1);
+      for (size_t i = 1; i < lim; i++)
+        if (cands[i].s == cands[i - 1].s) { tie = true; break; }
+      if (!tie) done = true;
+      break;
+    }
+  }
+  if (!done) {
+    // exact slow path: same libstdc++ introsort, same input order, same predicate as T:286
+    fill();
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s; });
+    bool finished = false;
+    (void)greedy(cands, cands.size(), finished);
   }
   if (clk_) clk_->shi += since(t0);
   return out;
@@ -209,26 +254,48 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
     clk->ransac_points += (std::uint64_t)n;
   }
   // Device hypotheses rank the iterations; the winner's E is re-derived with the platform libm (so it
-  // is the reference's E bit for bit) and its mask recomputed from that E.  Iterations whose device
-  // count is within 2 of the maximum are verified the same way, so a last-bit disagreement between
-  // the device ranking E and the reference E cannot change which iteration wins.
+  // is the reference's E bit for bit) and its mask recomputed from that E on the device.
+  //
+  // Verification set: iterations whose device count is within 2 of the maximum are "near ties"; the
+  // reference's winner is the LOWEST iteration with the maximal exact count (strict '>' at T:673).
+  //  * few near ties (<= 24): all of them are verified exactly;
+  //  * many (clean data: thousands of hypotheses reach the same maximal count): the device winner b
+  //    and every near tie BEFORE b are verified; later iterations could only win with an exact count
+  //    strictly above exact(b), i.e. if the device had under-counted them -- if exact(b) turns out to
+  //    differ from its device count at all, every near tie is verified (slow path, not seen in tests).
   std::optional<RelPose> result;
   if (best_count > 0) {
+    std::vector<int> near;
+    for (int it = 0; it < iters; ++it)
+      if (counts[(size_t)it] >= best_count - 2 && counts[(size_t)it] > 0) near.push_back(it);
     int win_iter = -1, win_count = -1;
     Mat3 winE;
     std::vector<std::uint8_t> mask((size_t)n), win_mask;
-    for (int it = 0; it < iters; ++it) {
-      if (counts[(size_t)it] < best_count - 2 || counts[(size_t)it] <= 0) continue;
+    auto verify = [&](int it) {
       const Mat3 E = eight_point_E(xi.data(), xj.data(), &idx8[(size_t)8 * it]);
       std::int32_t cnt = 0;
-      check(ctx, sfmx_sampson_mask(ctx, xi.data(), xj.data(), n, E.a, thr, mask.data(), &cnt), "sampson_mask");
+      check(ctx, sfmx_sampson_mask(ctx, nullptr, nullptr, n, E.a, thr, mask.data(), &cnt), "sampson_mask");
       if (clk) clk->ransac_verified++;
-      if (cnt > win_count) {  // strict '>' keeps the lowest iteration (T:673)
+      if (cnt > win_count || (cnt == win_count && it < win_iter)) {
         win_count = cnt;
         win_iter = it;
         winE = E;
         win_mask = mask;
       }
+      return cnt;
+    };
+    if (near.size() <= 24) {
+      for (int it : near) verify(it);
+    } else {
+      bool device_exact = true;
+      for (int it : near) {
+        if (it > best_iter) break;
+        const int cnt = verify(it);
+        if (it == best_iter && cnt != best_count) device_exact = false;
+      }
+      if (!device_exact)
+        for (int it : near)
+          if (it > best_iter) verify(it);
     }
     if (win_iter >= 0 && win_count >= min_inliers) {  // T:678
       RelPose rp;

@@ -17,3 +17,17 @@ def golden():
     import numpy as np
     import helpers as H
     return np.load(os.path.join(H.GOLDEN, "hotpath.npz"))
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_cuda_first():
+    """torch must initialise HIP before libsfmx does in the same process (otherwise torch reports
+    'No HIP GPUs are available'); harmless on the CPU-only container."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
+    yield

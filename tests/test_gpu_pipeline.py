@@ -105,3 +105,22 @@ def test_cli_drop_in(tmp_path):
     assert q.returncode == 1 and q.stderr.startswith("ERROR: Failed to open: ")
     q = subprocess.run([pipe.CLI_PATH, root, out, "3", "--export-geometry", "none"], capture_output=True, text=True, cwd=str(tmp_path))
     assert q.returncode == 0 and q.stdout.count("frame ") == 3
+
+
+def test_shi_fast_path_equals_full_sort(tmp_path):
+    """The prefix-select fast path of the corner pick must equal the full std::sort path (run in a
+    child process with SFMX_SHI_FULL_SORT=1) byte for byte, on a noisy and on a noise-free (tie-prone) scene."""
+    import sys
+    for noise in (True, False):
+        seq = synth.make_sequence(4, 320, 240, 0.3, n_blobs=6000, seed=11, noise=noise)
+        root = str(tmp_path / f"d{int(noise)}")
+        synth.write_dataset(root, seq)
+        outs = []
+        for env_extra in ({}, {"SFMX_SHI_FULL_SORT": "1"}):
+            out = os.path.join(root, "out" + str(len(outs)))
+            p = subprocess.run([pipe.CLI_PATH, root, out, "4"], capture_output=True, text=True, cwd=str(tmp_path),
+                               env={**os.environ, **env_extra})
+            assert p.returncode == 0, p.stderr
+            outs.append((p.stdout.replace(out, "X"), out))
+        assert outs[0][0] == outs[1][0]
+        _same_files(outs[0][1], outs[1][1])
