@@ -69,6 +69,15 @@ int sfmx_shi_tomasi_score(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double* score_
 int sfmx_shi_tomasi_candidates(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double quality, int cap,
                                uint32_t* cand_xy, double* cand_score, int* n_out, double* max_out);
 
+/* Same, after removing on the device every candidate whose rejection by the greedy min-distance pick
+ * (T:288-300) is certain whatever the sort's tie order: candidates within min_dist of a strictly
+ * higher "dominant" pixel (one that out-scores everything within min_dist and is therefore certainly
+ * accepted).  Bit 31 of cand_xy marks dominant candidates; x = bits 0..14, y = bits 16..30.
+ * *n_out = survivors (row-major order), *n_total_out = all candidates before pruning. */
+int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double quality, int min_dist,
+                                      int cap, uint32_t* cand_xy, double* cand_score, int* n_out,
+                                      int* n_total_out, double* max_out);
+
 /* ---- KLT: replaces KLTTracker::track_one fwd+bwd and the FB test (T:356-362, 402-460) ------- */
 typedef struct sfmx_klt_cfg {
   int levels;       /* LKConfig::pyr_levels (T:312) */

@@ -21,7 +21,7 @@ SYMBOLS = [
     "sfmx_ctx_create", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_stream", "sfmx_set_timing",
     "sfmx_last_kernel_us", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
-    "sfmx_shi_tomasi_candidates", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",
+    "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",
     "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt",
 ]
@@ -45,6 +45,13 @@ def load_library() -> ctypes.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise SfmxError(SFMX_ERR_NO_DEVICE, f"{LIB_PATH} not built: run __graft_entry__.build() (hipcc, gfx950)")
+        # PyTorch-ROCm ships its own libamdhip64.so.7; load it first so that torch (device memory,
+        # torch.distributed) and libsfmx share ONE HIP runtime in this process.
+        if "torch" not in __import__("sys").modules and not os.environ.get("SFMX_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.sfmx_last_error.restype = c_char_p
         _lib.sfmx_last_kernel_us.restype = c_double
@@ -193,6 +200,18 @@ class Context:
                                                       _p(sc, c_double), byref(n), byref(mx)))
         m = min(n.value, cap)
         return (xy[:m] & 0xFFFF).astype(np.int32), (xy[:m] >> 16).astype(np.int32), sc[:m].copy(), n.value, mx.value
+
+    def shi_candidates_pruned(self, pyr: Pyramid, quality: float, min_dist: int, cap: int | None = None):
+        cap = cap or pyr.w * pyr.h
+        xy = np.zeros(cap, np.uint32)
+        sc = np.zeros(cap)
+        n, ntot = c_int(), c_int()
+        mx = c_double()
+        self._chk(self.lib.sfmx_shi_tomasi_candidates_pruned(self.h_, pyr.h_, c_double(quality), c_int(min_dist), c_int(cap),
+                                                             _p(xy, c_uint32), _p(sc, c_double), byref(n), byref(ntot), byref(mx)))
+        m = min(n.value, cap)
+        return ((xy[:m] & 0x7FFF).astype(np.int32), ((xy[:m] >> 16) & 0x7FFF).astype(np.int32), (xy[:m] >> 31).astype(bool),
+                sc[:m].copy(), n.value, ntot.value)
 
     def klt_track(self, pa: Pyramid, pb: Pyramid, xy, levels=3, radius=5, iters=10, fb=1.0):
         xy = _f64(xy).reshape(-1, 2)

@@ -8,11 +8,13 @@
 //      weights, per-point Hpp/bp and per-(point,pose) Hxx/bx/Hxp exactly as T:920-1009, then
 //      inv3(Hpp) and G = Hxp * Hpp^-1, G*bp (T:1011-1041).  Output is one compact RECORD per point
 //      (84 doubles per observing pose) plus a pose->slot table; poses (W x 12 doubles) sit in LDS.
-//  k_ba_reduce  (one lane per element of S and b): walks the records in point order and performs the
-//      reference's additions in the reference's sequence (T:1015-1057): Hxx first, then the Schur
-//      term G_a * Hxp_b^T (which the reference ADDS, quirk Q6), bx then -G*bp for b; finally the
-//      damping and gauge terms (T:1064-1071).  Loads are issued 8 points ahead of the dependent
-//      add chain, which is the only serial part.
+//  k_ba_expand  (parallel over point x element): every addend the reference will add into S,b for
+//      this point -- the Schur term G_a * Hxp_b^T per element, Hxx, bx, G*bp -- written as one
+//      contiguous contribution row per point.
+//  k_ba_reduce  (one lane per element of S and b): ordered column sum over the contribution rows in
+//      the reference's sequence (T:1015-1057): Hxx first, then the Schur term (which the reference
+//      ADDS, quirk Q6), bx then -G*bp for b; finally damping and gauge (T:1064-1071).  Coalesced
+//      loads run 16 points ahead of the dependent add chain, which is the only serial part.
 //  k_solve_gauss (one workgroup, matrix in LDS): partial-pivoting elimination with the reference's
 //      first-maximum pivot rule, row normalisation, |f| < 1e-18 skip and ascending back-substitution.
 //
@@ -25,7 +27,7 @@
 
 struct sfmx_ba_problem {
   int W = 0, P = 0, R = 0, MS = 0;
-  DevBuf bufs[10];  // grow-only backing stores, so a problem object can be reset for every BA call
+  DevBuf bufs[11];  // grow-only backing stores, so a problem object can be reset for every BA call
   double* X = nullptr;
   int32_t* obs_ptr = nullptr;
   int32_t* obs_li = nullptr;
@@ -36,6 +38,7 @@ struct sfmx_ba_problem {
   double* S = nullptr;        // [D*D]
   double* b = nullptr;        // [D]
   double* work = nullptr;     // solve scratch: dx [D] + status
+  double* contrib = nullptr;  // [P][CS] per-point contribution rows
 };
 
 // dense.hpp:96-119
@@ -172,56 +175,79 @@ __global__ __launch_bounds__(64) void k_ba_points(int W, int P, int MS, const do
   }
 }
 
-#define BA_AHEAD 8
-__global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
-                                                   double lambda, int damp, double* __restrict__ S, double* __restrict__ b) {
-  const int D = 6 * W;
+// Per-point contribution rows.  Layout of one row (CS = D*D + 36*W + 2*D doubles):
+//   [0, D*D)              Schur term  G_a * Hxp_b^T  of S element (i,j)   (T:1049-1055), +0.0 if a pose misses the point
+//   [D*D, D*D+36W)        Hxx term of the diagonal block of pose A         (T:1017)
+//   [.., +D) and [.., +D) bx (T:1018) and G*bp (T:1039-1041)
+// A missing contribution is stored as +0.0: the running sums start at +0.0 and can never become -0.0,
+// so adding +0.0 is the identity and the reduction needs no branches.
+__device__ __forceinline__ int ba_row_stride(int W) { return 36 * W * W + 36 * W + 12 * W; }
+
+__global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
+                                                   double* __restrict__ C) {
+  const int D = 6 * W, CS = ba_row_stride(W);
+  const int p = blockIdx.y;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= CS) return;
+  const int8_t* so = slot_of + (size_t)p * W;
+  const double* base = rec + (size_t)p * MS * BA_SLOT;
+  double v = 0.0;
+  if (e < D * D) {
+    const int i = e / D, j = e % D;
+    const int sa = so[i / 6], sb = so[j / 6];
+    if (sa >= 0 && sb >= 0) {
+      const double* g = base + (size_t)sa * BA_SLOT + 60 + (i % 6) * 3;
+      const double* h = base + (size_t)sb * BA_SLOT + 42 + (j % 6) * 3;
+      v = g[0] * h[0] + g[1] * h[1] + g[2] * h[2];
+    }
+  } else if (e < D * D + 36 * W) {
+    const int k = e - D * D;
+    const int sa = so[k / 36];
+    if (sa >= 0) v = base[(size_t)sa * BA_SLOT + (k % 36)];
+  } else if (e < D * D + 36 * W + D) {
+    const int i = e - (D * D + 36 * W);
+    const int sa = so[i / 6];
+    if (sa >= 0) v = base[(size_t)sa * BA_SLOT + 36 + (i % 6)];
+  } else {
+    const int i = e - (D * D + 36 * W + D);
+    const int sa = so[i / 6];
+    if (sa >= 0) v = base[(size_t)sa * BA_SLOT + 78 + (i % 6)];
+  }
+  C[(size_t)p * CS + e] = v;
+}
+
+// Ordered column sums: one lane per element of S / b walks the contribution rows in point order.
+// Loads of neighbouring lanes are contiguous (coalesced) and independent of the add chain, so they
+// are issued BA_AHEAD points ahead; the dependent FP64 adds are the only serial part.
+#define BA_AHEAD 16
+__global__ __launch_bounds__(64) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
+                                                  double* __restrict__ b) {
+  const int D = 6 * W, CS = ba_row_stride(W);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= D * D + D) return;
   const bool is_b = e >= D * D;
   const int i = is_b ? e - D * D : e / D;
   const int j = is_b ? 0 : e % D;
-  const int A = i / 6, r = i % 6, B = is_b ? A : j / 6, cc = j % 6;
-  const bool diag_blk = (!is_b) && (A == B);
-  const size_t pstride = (size_t)MS * BA_SLOT;
+  const bool diag_blk = (!is_b) && (i / 6 == j / 6);
+  // first / second addend of this element inside a contribution row
+  const int o1 = is_b ? (D * D + 36 * W + i) : (D * D + (i / 6) * 36 + (i % 6) * 6 + (j % 6));
+  const int o2 = is_b ? (D * D + 36 * W + D + i) : e;
+  const bool two = is_b || diag_blk;
   double acc = 0.0;
   for (int p0 = 0; p0 < P; p0 += BA_AHEAD) {
-    int sa[BA_AHEAD], sb[BA_AHEAD];
-    double v0[BA_AHEAD], g0[BA_AHEAD], g1[BA_AHEAD], g2[BA_AHEAD], h0[BA_AHEAD], h1[BA_AHEAD], h2[BA_AHEAD];
+    double u[BA_AHEAD], v[BA_AHEAD];
 #pragma unroll
-    for (int u = 0; u < BA_AHEAD; u++) {
-      const int p = min(p0 + u, P - 1);
-      const bool ok = (p0 + u) < P;
-      const int a = slot_of[(size_t)p * W + A], bb = slot_of[(size_t)p * W + B];
-      sa[u] = ok ? a : -1;
-      sb[u] = ok ? bb : -1;
+    for (int k = 0; k < BA_AHEAD; k++) {
+      const int p = min(p0 + k, P - 1);
+      const double* row = C + (size_t)p * CS;
+      v[k] = row[o2];
+      u[k] = two ? row[o1] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < BA_AHEAD; u++) {
-      const int p = min(p0 + u, P - 1);
-      const double* base = rec + (size_t)p * pstride;
-      const double* ra = base + (size_t)max(sa[u], 0) * BA_SLOT;
-      const double* rb = base + (size_t)max(sb[u], 0) * BA_SLOT;
-      if (is_b) {
-        v0[u] = ra[36 + r];
-        g0[u] = ra[78 + r];
-        g1[u] = g2[u] = h0[u] = h1[u] = h2[u] = 0.0;
-      } else {
-        v0[u] = ra[r * 6 + cc];
-        g0[u] = ra[60 + r * 3 + 0]; g1[u] = ra[60 + r * 3 + 1]; g2[u] = ra[60 + r * 3 + 2];
-        h0[u] = rb[42 + cc * 3 + 0]; h1[u] = rb[42 + cc * 3 + 1]; h2[u] = rb[42 + cc * 3 + 2];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < BA_AHEAD; u++) {
-      if (is_b) {
-        if (sa[u] >= 0) {
-          acc += v0[u];  // b[li] += bx      (T:1018)
-          acc -= g0[u];  // b[li] -= G*bp    (T:1041)
-        }
-      } else {
-        if (diag_blk && sa[u] >= 0) acc += v0[u];                                          // S += Hxx         (T:1017)
-        if (sa[u] >= 0 && sb[u] >= 0) acc += g0[u] * h0[u] + g1[u] * h1[u] + g2[u] * h2[u];  // S += G_a Hxp_b^T (T:1055)
+    for (int k = 0; k < BA_AHEAD; k++) {
+      if (p0 + k < P) {
+        if (is_b) { acc += u[k]; acc -= v[k]; }          // b += bx ; b -= G*bp
+        else { if (diag_blk) acc += u[k]; acc += v[k]; }  // S += Hxx ; S += G_a Hxp_b^T  (reference ADDS, Q6)
       }
     }
   }
@@ -230,8 +256,8 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, int MS, const d
     b[i] = acc;
   } else {
     if (damp && i == j) {
-      acc += lambda;            // T:1064
-      if (i < 6) acc += 1e9;    // T:1069
+      acc += lambda;          // T:1064
+      if (i < 6) acc += 1e9;  // T:1069
     }
     S[(size_t)i * D + j] = acc;
   }
@@ -318,16 +344,29 @@ __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ 
     }
     __syncthreads();
   }
-  // ---- back substitution, ascending j per row (dense.hpp:86-91): inherently serial
-  if (tid == 0) {
-    for (int i = n - 1; i >= 0; i--) {
-      double s = bb[i];
-      for (int j = i + 1; j < n; j++) s -= A[(size_t)i * ld + j] * fcol[j];
-      fcol[i] = s;
+  // ---- back substitution (dense.hpp:86-91): x_i = b_i - sum_{j>i} A(i,j) x_j, subtracted in ASCENDING j.
+  // The subtraction chain is serial by contract; the products are not: as soon as x_j is known every
+  // row i<j replaces A(i,j) by A(i,j)*x_j (the same single rounding the reference performs), so the
+  // chain of row i only reads finished products.
+  for (int j = n - 1; j >= 0; j--) {
+    if (tid == 0) {
+      double s = bb[j];
+      const double* row = A + (size_t)j * ld;
+      int k = j + 1;
+      for (; k + 8 <= n; k += 8) {
+        const double p0 = row[k], p1 = row[k + 1], p2 = row[k + 2], p3 = row[k + 3], p4 = row[k + 4], p5 = row[k + 5], p6 = row[k + 6],
+                     p7 = row[k + 7];
+        s -= p0; s -= p1; s -= p2; s -= p3; s -= p4; s -= p5; s -= p6; s -= p7;
+      }
+      for (; k < n; k++) s -= row[k];
+      fcol[j] = s;
     }
-    status[0] = 0;
+    __syncthreads();
+    const double xj = fcol[j];
+    for (int i = tid; i < j; i += nt) A[(size_t)i * ld + j] = A[(size_t)i * ld + j] * xj;
+    __syncthreads();
   }
-  __syncthreads();
+  if (tid == 0) status[0] = 0;
   for (int e = tid; e < n; e += nt) x[e] = fcol[e];
 }
 
@@ -345,7 +384,9 @@ static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, 
     attr_set = true;
   }
   if (n <= SOLVE_LDS_MAX_N) {
-    k_solve_gauss<<<1, 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus, nullptr);
+    // up to 64 unknowns one wavefront does everything: its barriers are free and the 36x36 / 60x60 BA
+    // systems are latency-, not throughput-bound
+    k_solve_gauss<<<1, n <= 64 ? 64 : 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus, nullptr);
   } else {
     SFMX_HIP(c, c->d[7].ensure(solve_shmem(n)));
     k_solve_gauss<<<1, 256, 0, c->stream>>>(dA, db, n, dx, dstatus, c->d[7].as<double>());
@@ -361,7 +402,9 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   t.start();
   k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, q->poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy,
                                                     huber, q->rec, q->slot_of);
-  k_ba_reduce<<<(D * D + D + 255) / 256, 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, lambda, damp, q->S, q->b);
+  const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
+  k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib);
+  k_ba_reduce<<<(D * D + D + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;
@@ -377,9 +420,12 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
   q->W = W; q->P = P; q->R = R;
   q->MS = W < BA_MAX_OBS ? W : BA_MAX_OBS;
   const int D = 6 * W;
-  const size_t need[10] = {(size_t)P * 24, (size_t)(P + 1) * 4, (size_t)R * 4 + 8, (size_t)R * 16 + 8, (size_t)W * 96,
-                           (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8, (size_t)D * 8, (size_t)D * 8 + 64};
-  for (int i = 0; i < 10; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
+  const size_t CS = (size_t)36 * W * W + 36 * W + 12 * W;
+  const size_t need[11] = {(size_t)P * 24, (size_t)(P + 1) * 4, (size_t)R * 4 + 8, (size_t)R * 16 + 8, (size_t)W * 96,
+                           (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8, (size_t)D * 8, (size_t)D * 8 + 64,
+                           (size_t)P * CS * 8};
+  for (int i = 0; i < 11; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
+  q->contrib = q->bufs[10].as<double>();
   q->X = q->bufs[0].as<double>(); q->obs_ptr = q->bufs[1].as<int32_t>(); q->obs_li = q->bufs[2].as<int32_t>();
   q->obs_uv = q->bufs[3].as<double>(); q->poses = q->bufs[4].as<double>(); q->rec = q->bufs[5].as<double>();
   q->slot_of = q->bufs[6].as<int8_t>(); q->S = q->bufs[7].as<double>(); q->b = q->bufs[8].as<double>();

@@ -227,6 +227,99 @@ __global__ void k_row_write(const double* __restrict__ score, int w, int h, cons
   }
 }
 
+// ---- certain-outcome pruning for the greedy min-distance pick (T:288-300) ---------------------------
+// The greedy pick visits candidates by descending score and accepts one iff no ACCEPTED corner lies
+// closer than min_dist.  Two facts hold for every possible tie order of the sort:
+//   (1) a candidate whose score is strictly greater than every other pixel within min_dist
+//       ("dominant") is certainly accepted;
+//   (2) a candidate within min_dist of a dominant pixel of strictly greater score is certainly rejected,
+//       and a rejected candidate never influences any later decision.
+// k_shi_classify marks (1), k_shi_prune removes (2); only the remaining few thousand candidates travel to
+// the host, which runs the reference's sort + pick on them (pipeline.cpp checks the tie condition under
+// which the reduced run is provably identical, and otherwise falls back to the full candidate list).
+// flag: 0 = below threshold, 1 = candidate, 2 = dominant candidate, 3 = pruned.
+__global__ __launch_bounds__(256) void k_shi_classify(const double* __restrict__ score, int w, int h,
+                                                      const unsigned long long* __restrict__ max_bits, double quality, int md,
+                                                      uint8_t* __restrict__ flag) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const double thr = __longlong_as_double((long long)*max_bits) * quality;
+  const double s = score[(size_t)y * w + x];
+  uint8_t f = 0;
+  if (s >= thr) {
+    f = 2;
+    const int r = md - 1, md2 = md * md;
+    for (int dy = -r; dy <= r && f == 2; ++dy) {
+      const int yy = y + dy;
+      if (yy < 0 || yy >= h) continue;
+      for (int dx = -r; dx <= r; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= w || (dx == 0 && dy == 0) || dx * dx + dy * dy >= md2) continue;
+        if (score[(size_t)yy * w + xx] >= s) { f = 1; break; }
+      }
+    }
+  }
+  flag[(size_t)y * w + x] = f;
+}
+__global__ __launch_bounds__(256) void k_shi_prune(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ flag) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  if (flag[(size_t)y * w + x] != 1) return;
+  const double s = score[(size_t)y * w + x];
+  const int r = md - 1, md2 = md * md;
+  for (int dy = -r; dy <= r; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= h) continue;
+    for (int dx = -r; dx <= r; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= w || dx * dx + dy * dy >= md2) continue;
+      if (flag[(size_t)yy * w + xx] == 2 && score[(size_t)yy * w + xx] > s) {
+        flag[(size_t)y * w + x] = 3;  // only 1 -> 3 transitions happen here; readers only test for 2
+        return;
+      }
+    }
+  }
+}
+// ordered compaction of flag in {1,2}
+__global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* __restrict__ row_count, int* __restrict__ row_all) {
+  const int y = blockIdx.x;
+  int c = 0, a = 0;
+  for (int x = threadIdx.x; x < w; x += blockDim.x) {
+    const uint8_t f = flag[(size_t)y * w + x];
+    c += (f == 1 || f == 2) ? 1 : 0;
+    a += (f != 0) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o, 64); a += __shfl_down(a, o, 64); }
+  __shared__ int part[4], parta[4];
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = c; parta[threadIdx.x >> 6] = a; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0, ta = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) { t += part[i]; ta += parta[i]; }
+    row_count[y] = t;
+    atomicAdd(row_all, ta);
+  }
+}
+__global__ void k_flag_row_write(const double* __restrict__ score, const uint8_t* __restrict__ flag, int w, const int* __restrict__ row_off,
+                                 int cap, uint32_t* __restrict__ cand_xy, double* __restrict__ cand_s) {
+  const int y = blockIdx.x;
+  int off = row_off[y];
+  for (int base = 0; base < w; base += 64) {
+    const int x = base + (int)threadIdx.x;
+    const uint8_t f = (x < w) ? flag[(size_t)y * w + x] : 0;
+    const bool hit = (f == 1 || f == 2);
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int pos = off + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      if (pos < cap) {
+        cand_xy[pos] = (uint32_t)x | ((uint32_t)y << 16) | (f == 2 ? 0x80000000u : 0u);
+        cand_s[pos] = score[(size_t)y * w + x];
+      }
+    }
+    off += __popcll(m);
+  }
+}
+
 static int launch_score(sfmx_ctx* c, const sfmx_pyramid* p, double* d_score, unsigned long long* d_max) {
   SFMX_HIP(c, hipMemsetAsync(d_max, 0, 8, c->stream));
   dim3 b(ST_TX, ST_TY), g((p->w + ST_TX - 1) / ST_TX, (p->h + ST_TY - 1) / ST_TY);
@@ -290,6 +383,50 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
     SFMX_HIP(c, hipStreamSynchronize(c->stream));
   }
   *n_out = total;
+  if (max_out) *max_out = mx;
+  return SFMX_OK;
+}
+
+int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap, uint32_t* cand_xy,
+                                      double* cand_score, int* n_out, int* n_total_out, double* max_out) {
+  SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 32768 && p->h < 32768 && min_dist >= 1 && min_dist <= 64);
+  const size_t n = (size_t)p->w * p->h;
+  c->resident_points = 0;
+  SFMX_HIP(c, c->d[0].ensure(n * 8));
+  SFMX_HIP(c, c->d[1].ensure(64));
+  SFMX_HIP(c, c->d[2].ensure((size_t)(p->h + 2) * 4 + 64));
+  SFMX_HIP(c, c->d[3].ensure((size_t)cap * 4));
+  SFMX_HIP(c, c->d[4].ensure((size_t)cap * 8));
+  SFMX_HIP(c, c->d[5].ensure(n + 64));
+  unsigned long long* d_max = c->d[1].as<unsigned long long>();
+  int* d_rows = c->d[2].as<int>();
+  int* d_total = d_rows + p->h;
+  int* d_all = d_rows + p->h + 1;
+  uint8_t* d_flag = c->d[5].as<uint8_t>();
+  int rc = launch_score(c, p, c->d[0].as<double>(), d_max);
+  if (rc) return rc;
+  SFMX_HIP(c, hipMemsetAsync(d_all, 0, 4, c->stream));
+  dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
+  k_shi_classify<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, min_dist, d_flag);
+  k_shi_prune<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag);
+  k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_all);
+  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_total);
+  k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, cap, c->d[3].as<uint32_t>(), c->d[4].as<double>());
+  SFMX_HIP(c, hipGetLastError());
+  int tot[2] = {0, 0};
+  double mx = 0;
+  SFMX_HIP(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  KernelTimer(c).collect();
+  const int m = tot[0] < cap ? tot[0] : cap;
+  if (m > 0) {
+    SFMX_HIP(c, hipMemcpyAsync(cand_xy, c->d[3].p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipMemcpyAsync(cand_score, c->d[4].p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  *n_out = tot[0];
+  if (n_total_out) *n_total_out = tot[1];
   if (max_out) *max_out = mx;
   return SFMX_OK;
 }

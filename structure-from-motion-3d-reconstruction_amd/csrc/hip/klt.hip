@@ -53,13 +53,29 @@ __device__ __forceinline__ double sample_lds(const float* __restrict__ win, int 
   return v0 * (1 - cy.f) + v1 * cy.f;
 }
 
-__device__ __forceinline__ void stage_window(const uint8_t* __restrict__ img, int w, int h, int ox, int oy, float* __restrict__ win, int lane) {
-  for (int i = lane; i < KLT_P * KLT_P; i += 64) {
-    const int py = i / KLT_P, px = i % KLT_P;
-    const int gx = ox + px, gy = oy + py;
-    float v = 0.f;
-    if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = (float)img[(size_t)gy * w + gx];
-    win[py * KLT_PS + px] = v;
+// Both windows are staged together: all 32 byte loads of a lane are issued before the first LDS
+// store, so one staging costs about one L2 round trip instead of 32 dependent ones.
+__device__ __forceinline__ void stage_windows(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int w, int h, int ox,
+                                              int oy, float* __restrict__ win0, float* __restrict__ win1, int lane) {
+  constexpr int N = KLT_P * KLT_P / 64;  // 16 pixels per lane per image
+  const int px = lane % KLT_P, py0 = lane / KLT_P;  // lane covers column px of rows py0, py0+2, ...
+  const int gx = ox + px;
+  const bool xok = gx >= 0 && gx < w;
+  uint8_t a[N], b[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int gy = oy + py0 + 2 * k;
+    const bool ok = xok && gy >= 0 && gy < h;
+    const size_t off = ok ? (size_t)gy * w + gx : 0;
+    a[k] = img0[off];
+    b[k] = img1[off];
+    if (!ok) { a[k] = 0; b[k] = 0; }
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const int o = (py0 + 2 * k) * KLT_PS + px;
+    win0[o] = (float)a[k];
+    win1[o] = (float)b[k];
   }
 }
 
@@ -69,7 +85,8 @@ __device__ __forceinline__ int book_floor(double v) {
   return (int)floor(v);
 }
 
-__global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels, int r,
+template <int r>
+__global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
                                                   int iters, double fb_thresh, double* __restrict__ xy_fwd,
                                                   double* __restrict__ xy_back, uint8_t* __restrict__ keep,
                                                   unsigned long long* __restrict__ step_counter) {
@@ -80,8 +97,8 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
   const int lane = threadIdx.x;
   const int track = blockIdx.x;
   if (track >= n) return;
-  const int side = 2 * r + 1, npix = side * side;
-  const int npad = (npix + 1) & ~1;
+  constexpr int side = 2 * r + 1, npix = side * side;
+  constexpr int npad = (npix + 1) & ~1;
 
   const double p0x = xy_in[2 * track], p0y = xy_in[2 * track + 1];
   double px = p0x, py = p0y;
@@ -107,13 +124,15 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
             ox = bx - (KLT_P / 2 - 1);
             oy = by - (KLT_P / 2 - 1);
             __syncthreads();
-            stage_window(img0, w, h, ox, oy, win0, lane);
-            stage_window(img1, w, h, ox, oy, win1, lane);
+            stage_windows(img0, img1, w, h, ox, oy, win0, win1, lane);
             __syncthreads();
           }
         }
         // ---- per-pixel products (T:433-449)
-        for (int pix = lane; pix < npix; pix += 64) {
+#pragma unroll
+        for (int pix0 = 0; pix0 < npix; pix0 += 64) {
+          const int pix = pix0 + lane;
+          if (pix >= npix) break;
           const int dyi = pix / side - r, dxi = pix % side - r;
           const double xx = x + (double)dxi, yy = y + (double)dyi;
           const Tap cx0 = make_tap(xx, w), cxp = make_tap(xx + 1, w), cxm = make_tap(xx - 1, w);
@@ -133,14 +152,20 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         // ---- ordered sums: lane k < 5 adds accumulator k's products in reference order
         double acc = 0.0;
         if (lane < 5) {
-          const double* q = prod + lane * npad;
-          int i = 0;
-          for (; i + 1 < npix; i += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(q + i);
-            acc += v.x;
-            acc += v.y;
+          const double2* q = reinterpret_cast<const double2*>(prod + lane * npad);
+          // compile-time trip count: the LDS reads are hoisted in batches ahead of the dependent adds
+          constexpr int CH = 12;
+#pragma unroll
+          for (int i0 = 0; i0 < npix / 2; i0 += CH) {
+            double2 v[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+              if (i0 + k < npix / 2) v[k] = q[i0 + k];
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+              if (i0 + k < npix / 2) { acc += v[k].x; acc += v[k].y; }
           }
-          if (i < npix) acc += q[i];
+          if (npix & 1) acc += prod[lane * npad + npix - 1];
         }
         __syncthreads();  // products consumed; next iteration may overwrite
         const double A00 = __shfl(acc, 0, 64), A01 = __shfl(acc, 1, 64), A11 = __shfl(acc, 2, 64);
@@ -198,9 +223,20 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   const size_t shmem = (size_t)(2 * KLT_P * KLT_PS) * sizeof(float) + (size_t)5 * npad * sizeof(double);
   KernelTimer t(c);
   t.start();
-  k_klt_track<<<n, 64, shmem, c->stream>>>(make_desc(pa), make_desc(pb), c->d[0].as<double>(), n, cfg->levels, r, cfg->iters,
-                                           cfg->fb_thresh, c->d[1].as<double>(), c->d[2].as<double>(), c->d[3].as<uint8_t>(),
-                                           c->d[4].as<unsigned long long>());
+#define KLT_LAUNCH(RR)                                                                                                          \
+  k_klt_track<RR><<<n, 64, shmem, c->stream>>>(make_desc(pa), make_desc(pb), c->d[0].as<double>(), n, cfg->levels, cfg->iters, \
+                                               cfg->fb_thresh, c->d[1].as<double>(), c->d[2].as<double>(), c->d[3].as<uint8_t>(), \
+                                               c->d[4].as<unsigned long long>())
+  switch (r) {
+    case 1: KLT_LAUNCH(1); break;
+    case 2: KLT_LAUNCH(2); break;
+    case 3: KLT_LAUNCH(3); break;
+    case 4: KLT_LAUNCH(4); break;
+    case 5: KLT_LAUNCH(5); break;
+    case 6: KLT_LAUNCH(6); break;
+    default: KLT_LAUNCH(7); break;
+  }
+#undef KLT_LAUNCH
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   SFMX_HIP(c, hipMemcpyAsync(xy_fwd, c->d[1].p, nb, hipMemcpyDeviceToHost, c->stream));

@@ -49,80 +49,87 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
   sfmx_pyramid_level_size(pyr, 0, &w, &h);
   const int cap = w * h;
   if ((int)cand_xy_.size() < cap) { cand_xy_.resize((size_t)cap); cand_s_.resize((size_t)cap); }
-  int n = 0;
-  double maxv = 0;
-  check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &n, &maxv), "shi_tomasi_candidates");
-  if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
   struct Cand { int x, y; double s; int idx; };
   const double md2 = (double)min_dist * min_dist;
   const int cell = std::max(1, min_dist);
   const int gw = w / cell + 1, gh = h / cell + 1;
-  std::vector<int> head, next;
+  std::vector<int> head((size_t)gw * gh, -1), next;
   std::vector<V2> out;
-  // greedy min-distance pick (T:288-300) over cands[0..limit).  "no accepted corner closer than
-  // min_dist" does not depend on the order in which accepted corners are visited, so a uniform grid
-  // replaces the O(N*K) scan.  Returns the number of candidates consumed.
-  auto greedy = [&](const std::vector<Cand>& cands, size_t limit, bool& finished) -> size_t {
-    out.clear();
-    out.reserve((size_t)std::max(0, max_corners));
-    head.assign((size_t)gw * gh, -1);
-    next.clear();
-    finished = false;
-    size_t k = 0;
-    for (; k < limit; k++) {
-      const Cand& c = cands[k];
-      bool ok = true;
-      const int cx = c.x / cell, cy = c.y / cell;
-      for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1) && ok; gy++)
-        for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1) && ok; gx++)
-          for (int idx = head[(size_t)gy * gw + gx]; idx >= 0; idx = next[(size_t)idx]) {
-            const double dx = out[(size_t)idx].x - c.x, dy = out[(size_t)idx].y - c.y;
-            if (dx * dx + dy * dy < md2) { ok = false; break; }
-          }
-      if (!ok) continue;
-      next.push_back(head[(size_t)cy * gw + cx]);
-      head[(size_t)cy * gw + cx] = (int)out.size();
-      out.push_back(V2{double(c.x), double(c.y)});
-      if ((int)out.size() >= max_corners) { finished = true; k++; break; }
-    }
-    return k;
+  out.reserve((size_t)std::max(0, max_corners));
+  // "is c closer than min_dist to an accepted corner?" (T:292-296) -- an existence test, so a uniform
+  // grid over the accepted corners answers it exactly like the reference's linear scan.
+  auto blocked = [&](const Cand& c) {
+    const int cx = c.x / cell, cy = c.y / cell;
+    for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1); gy++)
+      for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1); gx++)
+        for (int idx = head[(size_t)gy * gw + gx]; idx >= 0; idx = next[(size_t)idx]) {
+          const double dx = out[(size_t)idx].x - c.x, dy = out[(size_t)idx].y - c.y;
+          if (dx * dx + dy * dy < md2) return true;
+        }
+    return false;
   };
-  std::vector<Cand> cands((size_t)n);
-  auto fill = [&]() {
-    for (int i = 0; i < n; i++)
-      cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0xffffu), (int)(cand_xy_[(size_t)i] >> 16), cand_s_[(size_t)i], i};
+  auto accept = [&](const Cand& c) {
+    const int cx = c.x / cell, cy = c.y / cell;
+    next.push_back(head[(size_t)cy * gw + cx]);
+    head[(size_t)cy * gw + cx] = (int)out.size();
+    out.push_back(V2{double(c.x), double(c.y)});
   };
-  fill();
-  // Fast path: only the best-scoring prefix is ever consumed.  Select and sort that prefix with the
-  // total order (score desc, row-major index asc).  If no two candidates of equal score occur in
-  // the consumed range (+1), every correct sort -- including the reference's std::sort at T:286 --
-  // orders that range identically, so the result is exact.  Equal scores => exact slow path below.
+
+  static const bool force_full = std::getenv("SFMX_SHI_FULL_SORT") != nullptr;  // test hook: always take the exact slow path
   bool done = false;
-  static const bool force_full_sort = std::getenv("SFMX_SHI_FULL_SORT") != nullptr;  // test hook
-  if (!force_full_sort) {
-    auto total = [](const Cand& a, const Cand& b) { return a.s > b.s || (a.s == b.s && a.idx < b.idx); };
-    size_t K = std::min((size_t)n, (size_t)std::max(4096, 6 * std::max(1, max_corners)));
-    while (!done) {
-      if (K < (size_t)n) std::nth_element(cands.begin(), cands.begin() + (long)K, cands.end(), total);
-      std::sort(cands.begin(), cands.begin() + (long)K, total);
-      bool finished = false;
-      const size_t used = greedy(cands, K, finished);
-      if (!finished && K < (size_t)n) { K = std::min((size_t)n, K * 2); continue; }
-      if (finished && used == K && K < (size_t)n) { K = std::min((size_t)n, K * 2); continue; }  // need cands[used] for the tie test
-      bool tie = false;
-      const size_t lim = std::min(K, used + 1);
-      for (size_t i = 1; i < lim; i++)
-        if (cands[i].s == cands[i - 1].s) { tie = true; break; }
-      if (!tie) done = true;
-      break;
+  if (!force_full && min_dist >= 1 && min_dist <= 64) {
+    // ---- fast path: the device has already removed every candidate that is certainly rejected
+    int n = 0, n_total = 0;
+    double maxv = 0;
+    check(ctx_, sfmx_shi_tomasi_candidates_pruned(ctx_, pyr, quality, min_dist, cap, cand_xy_.data(), cand_s_.data(), &n, &n_total, &maxv),
+          "shi_tomasi_candidates_pruned");
+    if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
+    std::vector<Cand> cands((size_t)n);
+    for (int i = 0; i < n; i++)
+      cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0x7fffu), (int)((cand_xy_[(size_t)i] >> 16) & 0x7fffu), cand_s_[(size_t)i], i};
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s || (a.s == b.s && a.idx < b.idx); });
+    // Walk score groups.  A group with a single member behaves as in the reference.  For a group of
+    // equal scores the reference's order is whatever its std::sort produced; the outcome is independent
+    // of that order iff at most ONE member is still eligible (not blocked by corners of strictly higher
+    // score) -- then exactly that member is accepted.  Two or more eligible members: ambiguous => redo
+    // with the full candidate list and the reference's own sort call.
+    bool ambiguous = false;
+    size_t i = 0;
+    while (i < cands.size() && !ambiguous && (int)out.size() < std::max(1, max_corners)) {
+      size_t j = i + 1;
+      while (j < cands.size() && cands[j].s == cands[i].s) j++;
+      if (j - i == 1) {
+        if (!blocked(cands[i])) accept(cands[i]);
+      } else {
+        int eligible = -1, count = 0;
+        for (size_t k = i; k < j; k++)
+          if (!blocked(cands[k])) { count++; eligible = (int)k; }
+        if (count >= 2) ambiguous = true;
+        else if (count == 1) accept(cands[(size_t)eligible]);
+      }
+      i = j;
+      if ((int)out.size() >= max_corners) break;
     }
+    done = !ambiguous;
+    if (clk_ && ambiguous) clk_->shi_fallbacks++;
   }
   if (!done) {
-    // exact slow path: same libstdc++ introsort, same input order, same predicate as T:286
-    fill();
-    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s; });
-    bool finished = false;
-    (void)greedy(cands, cands.size(), finished);
+    // ---- exact slow path: every candidate, the reference's sort call on the reference's input order
+    out.clear();
+    next.clear();
+    std::fill(head.begin(), head.end(), -1);
+    int n = 0;
+    double maxv = 0;
+    check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &n, &maxv), "shi_tomasi_candidates");
+    if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
+    std::vector<Cand> cands((size_t)n);
+    for (int i = 0; i < n; i++) cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0xffffu), (int)(cand_xy_[(size_t)i] >> 16), cand_s_[(size_t)i], i};
+    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s; });  // T:286
+    for (const Cand& c : cands) {
+      if (blocked(c)) continue;
+      accept(c);
+      if ((int)out.size() >= max_corners) break;
+    }
   }
   if (clk_) clk_->shi += since(t0);
   return out;
@@ -693,7 +700,7 @@ struct sfmx_pipeline_stats {
   int n_keyframes, n_points, n_edges, n_frames;
   double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host;
   double us_klt_kernel, us_ransac_kernel, us_ba_kernel, us_shi_kernel;
-  unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified;
+  unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -736,7 +743,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
       *stats = sfmx_pipeline_stats{(int)res.kfs.size(), (int)res.map.pts.size(), (int)res.edges.size(), std::min(pc.frames, n_images),
                                    c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host,
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
-                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified};
+                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks};
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {

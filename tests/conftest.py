@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch bundles its own libamdhip64.so.7; whichever HIP runtime is loaded first in a process is the one
+# every later library binds to (same SONAME).  Import torch before any test module dlopens libsfmx*.so.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -17,17 +24,3 @@ def golden():
     import numpy as np
     import helpers as H
     return np.load(os.path.join(H.GOLDEN, "hotpath.npz"))
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _torch_cuda_first():
-    """torch must initialise HIP before libsfmx does in the same process (otherwise torch reports
-    'No HIP GPUs are available'); harmless on the CPU-only container."""
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-            torch.zeros(1, device="cuda:0")
-    except Exception:
-        pass
-    yield
