@@ -2,6 +2,7 @@
 #include "pipeline.hpp"
 
 #include "../hip/sfmx_math.h"
+#include "introsort_replay.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -93,25 +94,73 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
     // of that order iff at most ONE member is still eligible (not blocked by corners of strictly higher
     // score) -- then exactly that member is accepted.  Two or more eligible members: ambiguous => redo
     // with the full candidate list and the reference's own sort call.
-    bool ambiguous = false;
-    size_t i = 0;
-    while (i < cands.size() && !ambiguous && (int)out.size() < std::max(1, max_corners)) {
-      size_t j = i + 1;
-      while (j < cands.size() && cands[j].s == cands[i].s) j++;
-      if (j - i == 1) {
-        if (!blocked(cands[i])) accept(cands[i]);
-      } else {
-        int eligible = -1, count = 0;
-        for (size_t k = i; k < j; k++)
-          if (!blocked(cands[k])) { count++; eligible = (int)k; }
-        if (count >= 2) ambiguous = true;
-        else if (count == 1) accept(cands[(size_t)eligible]);
+    auto walk = [&](bool& ambiguous) {
+      ambiguous = false;
+      size_t i = 0;
+      while (i < cands.size() && (int)out.size() < std::max(1, max_corners)) {
+        size_t j = i + 1;
+        while (j < cands.size() && cands[j].s == cands[i].s) j++;
+        if (j - i == 1) {
+          if (!blocked(cands[i])) accept(cands[i]);
+        } else {
+          int eligible = -1, count = 0;
+          for (size_t k = i; k < j; k++)
+            if (!blocked(cands[k])) { count++; eligible = (int)k; }
+          if (count >= 2) { ambiguous = true; return; }
+          if (count == 1) accept(cands[(size_t)eligible]);
+        }
+        i = j;
+        if ((int)out.size() >= max_corners) break;
       }
-      i = j;
-      if ((int)out.size() >= max_corners) break;
-    }
+    };
+    bool ambiguous = false;
+    walk(ambiguous);
     done = !ambiguous;
-    if (clk_ && ambiguous) clk_->shi_fallbacks++;
+    if (ambiguous) {
+      // ---- tie order from a selective replay of libstdc++'s introsort on the FULL candidate list
+      if (clk_) clk_->shi_fallbacks++;
+      std::vector<std::uint32_t> sel_xy((size_t)n);
+      for (int k = 0; k < n; k++) sel_xy[(size_t)k] = cand_xy_[(size_t)k] & 0x7fff7fffu;  // pruned list, row-major order
+      std::vector<Cand> pruned((size_t)n);
+      for (int k = 0; k < n; k++) pruned[(size_t)k] = {(int)(sel_xy[(size_t)k] & 0x7fffu), (int)(sel_xy[(size_t)k] >> 16), cand_s_[(size_t)k], k};
+      int nf = 0;
+      double mx2 = 0;
+      check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &nf, &mx2), "shi_tomasi_candidates");
+      if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
+      // interesting = members of the pruned list that share their score with another member
+      std::vector<std::uint8_t> tied((size_t)n, 0);
+      for (size_t a = 0; a + 1 < cands.size(); a++)
+        if (cands[a].s == cands[a + 1].s) { tied[(size_t)cands[a].idx] = 1; tied[(size_t)cands[a + 1].idx] = 1; }
+      std::vector<SortKey> keys((size_t)nf);
+      std::vector<int> full_of((size_t)n, -1);
+      {
+        int k = 0;  // both lists are in row-major order: merge-walk to find each pruned member in the full list
+        for (int f = 0; f < nf; f++) {
+          const std::uint32_t xy = cand_xy_[(size_t)f];
+          std::uint32_t mark = 0;
+          if (k < n && sel_xy[(size_t)k] == xy) { full_of[(size_t)k] = f; mark = tied[(size_t)k]; k++; }
+          keys[(size_t)f] = SortKey{cand_s_[(size_t)f], (std::uint32_t)f, mark};
+        }
+      }
+      if (introsort_replay_selective(keys)) {
+        std::vector<int> pos((size_t)nf, 0);
+        for (int f = 0; f < nf; f++) pos[(size_t)keys[(size_t)f].id] = f;
+        cands = pruned;
+        std::sort(cands.begin(), cands.end(), [&](const Cand& a, const Cand& b) {
+          if (a.s != b.s) return a.s > b.s;
+          return pos[(size_t)full_of[(size_t)a.idx]] < pos[(size_t)full_of[(size_t)b.idx]];
+        });
+        out.clear();
+        next.clear();
+        std::fill(head.begin(), head.end(), -1);
+        for (const Cand& c : cands) {  // the order is now the reference's: plain greedy (T:290-300)
+          if (blocked(c)) continue;
+          accept(c);
+          if ((int)out.size() >= max_corners) break;
+        }
+        done = true;
+      }
+    }
   }
   if (!done) {
     // ---- exact slow path: every candidate, the reference's sort call on the reference's input order
@@ -797,5 +846,18 @@ void sfmx_host_so3(const double* w3, double* R9, double* log3) {
   log3[0] = l.x; log3[1] = l.y; log3[2] = l.z;
 }
 double sfmx_host_hypot(double x, double y) { return sfmx::hypot_glibc(x, y); }
+
+// introsort replica checks: mode 0 = real std::sort (T:286 predicate), 1 = full replay, 2 = selective
+// replay with marks.  ids_out receives the element ids in array order afterwards.  returns 1 on success.
+int sfmx_host_sort_order(const double* scores, const unsigned char* marks, int n, int mode, unsigned* ids_out) {
+  std::vector<sfmx_host::SortKey> k((size_t)n);
+  for (int i = 0; i < n; i++) k[(size_t)i] = sfmx_host::SortKey{scores[i], (std::uint32_t)i, marks ? (std::uint32_t)marks[i] : 0u};
+  bool ok = true;
+  if (mode == 0) std::sort(k.begin(), k.end(), [](const sfmx_host::SortKey& a, const sfmx_host::SortKey& b) { return a.s > b.s; });
+  else if (mode == 1) ok = sfmx_host::introsort_replay_full(k);
+  else ok = sfmx_host::introsort_replay_selective(k);
+  for (int i = 0; i < n; i++) ids_out[i] = k[(size_t)i].id;
+  return ok ? 1 : 0;
+}
 
 }  // extern "C"

@@ -70,3 +70,37 @@ def test_hypot_restatement_matches_libm():
     for a, b in [(0.0, 0.0), (np.inf, 1.0), (3.0, 0.0), (0.0, -4.0), (1e300, 1e300), (1e-320, 1e-320), (5e-324, 0.0)]:
         assert fn(a, b) == np.hypot(a, b)
     assert np.isnan(fn(float("nan"), 1.0))
+
+
+def test_introsort_replay_reproduces_std_sort_tie_order():
+    """The partial replay of libstdc++'s introsort (host/introsort_replay.hpp) that decides the order of
+    equal-score corner candidates: (1) the full replay equals the real std::sort element for element on
+    tie-heavy inputs; (2) the selective replay puts every marked pair of equal keys in the same relative
+    order as std::sort does."""
+    rng = np.random.default_rng(12)
+    fn = L.dll.sfmx_host_sort_order
+    fn.restype = ctypes.c_int
+    for n, levels in [(5, 2), (16, 3), (17, 3), (100, 7), (1000, 13), (20000, 500), (150000, 4000), (150000, 10**9), (3000, 1)]:
+        for rep in range(3):
+            scores = rng.integers(0, levels, n).astype(np.float64) * 0.25
+            if rep == 1:
+                scores = np.sort(scores)          # adversarial orders
+            if rep == 2:
+                scores = np.sort(scores)[::-1].copy()
+            ref_ids = np.zeros(n, np.uint32)
+            full_ids = np.zeros(n, np.uint32)
+            assert fn(scores.ctypes.data_as(ctypes.c_void_p), None, n, 0, ref_ids.ctypes.data_as(ctypes.c_void_p)) == 1
+            ok = fn(scores.ctypes.data_as(ctypes.c_void_p), None, n, 1, full_ids.ctypes.data_as(ctypes.c_void_p))
+            if ok:  # the replay declines (returns 0) only when the real sort would switch to heapsort
+                assert np.array_equal(ref_ids, full_ids), (n, levels, rep)
+            marks = (rng.random(n) < min(1.0, 40.0 / n)).astype(np.uint8)
+            sel_ids = np.zeros(n, np.uint32)
+            ok = fn(scores.ctypes.data_as(ctypes.c_void_p), marks.ctypes.data_as(ctypes.c_void_p), n, 2, sel_ids.ctypes.data_as(ctypes.c_void_p))
+            if ok:
+                pos_ref = np.empty(n, np.int64); pos_ref[ref_ids] = np.arange(n)
+                pos_sel = np.empty(n, np.int64); pos_sel[sel_ids] = np.arange(n)
+                m = np.nonzero(marks)[0]
+                for a in range(len(m)):
+                    for b in range(a + 1, len(m)):
+                        if scores[m[a]] == scores[m[b]]:
+                            assert (pos_ref[m[a]] < pos_ref[m[b]]) == (pos_sel[m[a]] < pos_sel[m[b]]), (n, levels, rep)
