@@ -69,11 +69,12 @@ int sfmx_shi_tomasi_score(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double* score_
 int sfmx_shi_tomasi_candidates(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double quality, int cap,
                                uint32_t* cand_xy, double* cand_score, int* n_out, double* max_out);
 
-/* Same, after removing on the device every candidate whose rejection by the greedy min-distance pick
- * (T:288-300) is certain whatever the sort's tie order: candidates within min_dist of a strictly
- * higher "dominant" pixel (one that out-scores everything within min_dist and is therefore certainly
- * accepted).  Bit 31 of cand_xy marks dominant candidates; x = bits 0..14, y = bits 16..30.
- * *n_out = survivors (row-major order), *n_total_out = all candidates before pruning. */
+/* Same, after resolving on the device every candidate whose fate under the greedy min-distance pick
+ * (T:288-300) is certain whatever the sort's tie order (parallel fixpoint: "accepted" once every pixel
+ * within min_dist with score >= its own is rejected; "rejected" once an accepted pixel of strictly
+ * greater score lies within min_dist).  Rejected candidates are dropped; bit 31 of cand_xy marks the
+ * certainly accepted ones, the rest are still undecided; x = bits 0..14, y = bits 16..30.
+ * *n_out = survivors (row-major order), *n_total_out = all candidates before resolution. */
 int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double quality, int min_dist,
                                       int cap, uint32_t* cand_xy, double* cand_score, int* n_out,
                                       int* n_total_out, double* max_out);

@@ -264,14 +264,119 @@ __global__ __launch_bounds__(64) void k_ba_reduce(int W, int P, const double* __
 }
 
 // ------------------------------------------------------------------------------------------ dense solve
-// status[0] = 0 ok, 1 singular (pivot < 1e-15).  A,b are read from global memory, x written.
+// cpp/include/dense.hpp:54-93 in the reference's operation order.  status[0] = 0 ok, 1 singular
+// (pivot < 1e-15, where the reference throws).  A,b are read from global memory, x written.
+//
+// k_solve_wave (n <= 64): ONE wavefront, matrix in LDS, lane = row.  Nothing but the wave's own
+// in-order LDS traffic synchronises the phases (block = 1 wave, so __syncthreads() is free):
+//   pivot   : lane i reads |A[i][k]|, wave max by xor-shuffles, first lane holding the max = the
+//             reference's "first strictly larger" scan; NaN never wins unless it sits on the diagonal;
+//   swap    : lanes as columns exchange rows k and piv (columns k..n-1 only, like the reference);
+//   scale   : A[k][j] /= akk (IEEE division), b[k] /= akk;
+//   eliminate: lane i (row i > k, |f_i| >= 1e-18) walks its row: A[i][j] -= f_i * A[k][j]; the row-k
+//             operands are LDS broadcasts, the own-row accesses are conflict-free (odd row stride);
+//   back-substitution: products A(i,j)*x_j are formed by all rows as soon as x_j exists, so only the
+//             reference's ascending-j subtraction chain of the current row is serial.
+#define SOLVE_WAVE_MAX_N 64
+__global__ __launch_bounds__(64) void k_solve_wave(const double* __restrict__ Ain, const double* __restrict__ bin, int n,
+                                                   double* __restrict__ x, int* __restrict__ status) {
+  __shared__ double A[SOLVE_WAVE_MAX_N * (SOLVE_WAVE_MAX_N + 1)];
+  __shared__ double bb[SOLVE_WAVE_MAX_N];
+  __shared__ double xs[SOLVE_WAVE_MAX_N];
+  const int lane = threadIdx.x;
+  const int ld = n | 1;  // odd row stride
+  for (int e = lane; e < n * n; e += 64) A[(e / n) * ld + (e % n)] = Ain[e];
+  if (lane < n) bb[lane] = bin[lane];
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    // ---- pivot (dense.hpp:61-67)
+    const bool mine = lane >= k && lane < n;
+    const double v = mine ? fabs(A[lane * ld + k]) : -1.0;
+    const double akk0 = fabs(A[k * ld + k]);
+    double m = (v == v) ? v : -1.0;  // NaN below the diagonal never wins `v > best`
+    for (int o = 32; o > 0; o >>= 1) {
+      const double t = __shfl_xor(m, o, 64);
+      m = t > m ? t : m;
+    }
+    int piv = k;
+    double best = akk0;
+    if (akk0 == akk0) {  // a NaN on the diagonal stays the pivot: `v > NaN` is never true
+      const unsigned long long hit = __ballot(mine && v == m);
+      piv = hit ? (int)__builtin_ctzll(hit) : k;
+      best = m;
+    }
+    if (best < 1e-15) {
+      if (lane == 0) status[0] = 1;
+      return;
+    }
+    // ---- row swap on columns k..n-1 (lanes as columns), b too
+    const int j = k + lane;
+    if (piv != k) {
+      if (j < n) {
+        const double t = A[k * ld + j];
+        A[k * ld + j] = A[piv * ld + j];
+        A[piv * ld + j] = t;
+      }
+      if (lane == 0) { const double t = bb[k]; bb[k] = bb[piv]; bb[piv] = t; }
+    }
+    __syncthreads();
+    // ---- normalise row k
+    const double akk = A[k * ld + k];
+    __syncthreads();
+    if (j < n) A[k * ld + j] = A[k * ld + j] / akk;
+    if (lane == 0) bb[k] = bb[k] / akk;
+    __syncthreads();
+    // ---- eliminate rows below (dense.hpp:78-83)
+    if (lane > k && lane < n) {
+      double* row = A + lane * ld;
+      const double* rk = A + k * ld;
+      const double f = row[k];
+      if (!(fabs(f) < 1e-18)) {
+        int c = k;
+        for (; c + 4 <= n; c += 4) {
+          const double r0 = rk[c], r1 = rk[c + 1], r2 = rk[c + 2], r3 = rk[c + 3];
+          const double a0 = row[c], a1 = row[c + 1], a2 = row[c + 2], a3 = row[c + 3];
+          row[c] = a0 - f * r0; row[c + 1] = a1 - f * r1; row[c + 2] = a2 - f * r2; row[c + 3] = a3 - f * r3;
+        }
+        for (; c < n; c++) row[c] = row[c] - f * rk[c];
+        bb[lane] = bb[lane] - f * bb[k];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- back substitution (dense.hpp:86-91)
+  for (int jx = n - 1; jx >= 0; jx--) {
+    if (lane == 0) {
+      double sacc = bb[jx];
+      const double* row = A + jx * ld;
+      int c = jx + 1;
+      for (; c + 8 <= n; c += 8) {
+        const double p0 = row[c], p1 = row[c + 1], p2 = row[c + 2], p3 = row[c + 3], p4 = row[c + 4], p5 = row[c + 5], p6 = row[c + 6],
+                     p7 = row[c + 7];
+        sacc -= p0; sacc -= p1; sacc -= p2; sacc -= p3; sacc -= p4; sacc -= p5; sacc -= p6; sacc -= p7;
+      }
+      for (; c < n; c++) sacc -= row[c];
+      xs[jx] = sacc;
+    }
+    __syncthreads();
+    const double xj = xs[jx];
+    if (lane < jx) A[lane * ld + jx] = A[lane * ld + jx] * xj;  // the product the reference forms at dense.hpp:89
+    __syncthreads();
+  }
+  if (lane == 0) status[0] = 0;
+  if (lane < n) x[lane] = xs[lane];
+}
+
+// Larger systems: one 256-thread workgroup, matrix in LDS (n <= 141) or in a global working copy.
+template <bool IN_LDS>
 __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ Ain, const double* __restrict__ bin, int n,
-                                                     double* __restrict__ x, int* __restrict__ status, double* gwork) {
+                                                     double* __restrict__ x, int* __restrict__ status, double* __restrict__ gwork) {
   extern __shared__ __align__(16) double sm[];
-  const int ld = n + 1;  // row stride (odd multiple of 8 B keeps column walks off one bank)
-  double* A = gwork ? gwork : sm;   // [n][ld]: LDS when it fits, else a global working copy (L2-resident)
-  double* bb = A + (size_t)n * ld;  // [n]
-  double* fcol = bb + n;          // [n]
+  const int ld = n + 1;
+  double* A;
+  if constexpr (IN_LDS) A = sm; else A = gwork;
+  double* bb = A + (size_t)n * ld;
+  double* fcol = bb + n;
   __shared__ double red_v[4];
   __shared__ int red_i[4];
   __shared__ int s_piv, s_stop;
@@ -281,12 +386,11 @@ __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ 
   if (tid == 0) s_stop = 0;
   __syncthreads();
   for (int k = 0; k < n; k++) {
-    // ---- pivot: first strictly-largest |A[i][k]|, i >= k (dense.hpp:61-66)
     double bv = -1.0;
     int bi = 0x7fffffff;
     for (int i = k + tid; i < n; i += nt) {
       const double v = fabs(A[(size_t)i * ld + k]);
-      if (v > bv) { bv = v; bi = i; }  // NaN never wins
+      if (v > bv) { bv = v; bi = i; }
     }
     for (int o = 32; o > 0; o >>= 1) {
       const double ov = __shfl_down(bv, o, 64);
@@ -303,10 +407,10 @@ __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ 
       const double akk0 = fabs(A[(size_t)k * ld + k]);
       int piv = ix;
       double best = v;
-      if (akk0 != akk0) { piv = k; best = akk0; }       // NaN on the diagonal: `v > best` is never true
+      if (akk0 != akk0) { piv = k; best = akk0; }
       else if (piv == 0x7fffffff) { piv = k; best = akk0; }
       s_piv = piv;
-      if (best < 1e-15) s_stop = 1;                      // dense.hpp:67 throws
+      if (best < 1e-15) s_stop = 1;
     }
     __syncthreads();
     if (s_stop) {
@@ -329,7 +433,6 @@ __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ 
     if (tid == 0) bb[k] /= akk;
     for (int i = k + 1 + tid; i < n; i += nt) fcol[i] = A[(size_t)i * ld + k];
     __syncthreads();
-    // ---- eliminate rows below (dense.hpp:78-83); rows with |f| < 1e-18 are skipped
     const int cols = n - k, rows = n - k - 1;
     for (int e = tid; e < rows * cols; e += nt) {
       const int i = k + 1 + e / cols, j = k + e % cols;
@@ -344,22 +447,18 @@ __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ 
     }
     __syncthreads();
   }
-  // ---- back substitution (dense.hpp:86-91): x_i = b_i - sum_{j>i} A(i,j) x_j, subtracted in ASCENDING j.
-  // The subtraction chain is serial by contract; the products are not: as soon as x_j is known every
-  // row i<j replaces A(i,j) by A(i,j)*x_j (the same single rounding the reference performs), so the
-  // chain of row i only reads finished products.
   for (int j = n - 1; j >= 0; j--) {
     if (tid == 0) {
-      double s = bb[j];
+      double sacc = bb[j];
       const double* row = A + (size_t)j * ld;
-      int k = j + 1;
-      for (; k + 8 <= n; k += 8) {
-        const double p0 = row[k], p1 = row[k + 1], p2 = row[k + 2], p3 = row[k + 3], p4 = row[k + 4], p5 = row[k + 5], p6 = row[k + 6],
-                     p7 = row[k + 7];
-        s -= p0; s -= p1; s -= p2; s -= p3; s -= p4; s -= p5; s -= p6; s -= p7;
+      int c = j + 1;
+      for (; c + 8 <= n; c += 8) {
+        const double p0 = row[c], p1 = row[c + 1], p2 = row[c + 2], p3 = row[c + 3], p4 = row[c + 4], p5 = row[c + 5], p6 = row[c + 6],
+                     p7 = row[c + 7];
+        sacc -= p0; sacc -= p1; sacc -= p2; sacc -= p3; sacc -= p4; sacc -= p5; sacc -= p6; sacc -= p7;
       }
-      for (; k < n; k++) s -= row[k];
-      fcol[j] = s;
+      for (; c < n; c++) sacc -= row[c];
+      fcol[j] = sacc;
     }
     __syncthreads();
     const double xj = fcol[j];
@@ -374,22 +473,22 @@ static size_t solve_shmem(int n) { return ((size_t)n * (n + 1) + 2 * (size_t)n) 
 #define SOLVE_LDS_MAX_N 141   // 141*142*8 + 2*141*8 + statics < 160 KiB
 #define SOLVE_MAX_N 4096
 
-// n <= 141: the whole system lives in LDS.  Larger systems (pose graphs) run the same kernel on a
-// global working copy in ctx->d[7]: correct and reference-ordered, single workgroup (the blocked
-// multi-CU solver for D ~ 1e4 is a "next" row).
+// n <= 64: wave-synchronous kernel.  n <= 141: block kernel, system in LDS.  Larger systems (pose
+// graphs): same block kernel on a global working copy in ctx->d[7] -- correct and reference-ordered,
+// single workgroup (the blocked multi-CU solver for D ~ 1e4 is a "next" row).
 static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
   static bool attr_set = false;
   if (!attr_set) {
-    SFMX_HIP(c, hipFuncSetAttribute((const void*)k_solve_gauss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem(SOLVE_LDS_MAX_N)));
+    SFMX_HIP(c, hipFuncSetAttribute((const void*)k_solve_gauss<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem(SOLVE_LDS_MAX_N)));
     attr_set = true;
   }
-  if (n <= SOLVE_LDS_MAX_N) {
-    // up to 64 unknowns one wavefront does everything: its barriers are free and the 36x36 / 60x60 BA
-    // systems are latency-, not throughput-bound
-    k_solve_gauss<<<1, n <= 64 ? 64 : 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus, nullptr);
+  if (n <= SOLVE_WAVE_MAX_N) {
+    k_solve_wave<<<1, 64, 0, c->stream>>>(dA, db, n, dx, dstatus);
+  } else if (n <= SOLVE_LDS_MAX_N) {
+    k_solve_gauss<true><<<1, 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus, nullptr);
   } else {
     SFMX_HIP(c, c->d[7].ensure(solve_shmem(n)));
-    k_solve_gauss<<<1, 256, 0, c->stream>>>(dA, db, n, dx, dstatus, c->d[7].as<double>());
+    k_solve_gauss<false><<<1, 256, 0, c->stream>>>(dA, db, n, dx, dstatus, c->d[7].as<double>());
   }
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;

@@ -227,57 +227,54 @@ __global__ void k_row_write(const double* __restrict__ score, int w, int h, cons
   }
 }
 
-// ---- certain-outcome pruning for the greedy min-distance pick (T:288-300) ---------------------------
+// ---- certain-outcome resolution of the greedy min-distance pick (T:288-300) --------------------------
 // The greedy pick visits candidates by descending score and accepts one iff no ACCEPTED corner lies
-// closer than min_dist.  Two facts hold for every possible tie order of the sort:
-//   (1) a candidate whose score is strictly greater than every other pixel within min_dist
-//       ("dominant") is certainly accepted;
-//   (2) a candidate within min_dist of a dominant pixel of strictly greater score is certainly rejected,
-//       and a rejected candidate never influences any later decision.
-// k_shi_classify marks (1), k_shi_prune removes (2); only the remaining few thousand candidates travel to
-// the host, which runs the reference's sort + pick on them (pipeline.cpp checks the tie condition under
-// which the reduced run is provably identical, and otherwise falls back to the full candidate list).
-// flag: 0 = below threshold, 1 = candidate, 2 = dominant candidate, 3 = pruned.
-__global__ __launch_bounds__(256) void k_shi_classify(const double* __restrict__ score, int w, int h,
-                                                      const unsigned long long* __restrict__ max_bits, double quality, int md,
-                                                      uint8_t* __restrict__ flag) {
+// closer than min_dist.  Whatever order the sort gives equal scores, two facts hold:
+//   (A) a candidate is certainly ACCEPTED once every other pixel within min_dist whose score is >= its
+//       own is certainly rejected (nothing that could precede it can block it);
+//   (R) a candidate is certainly REJECTED once a certainly-accepted pixel of strictly greater score lies
+//       within min_dist; a rejected candidate never influences a later decision.
+// Both are monotone, so they can be applied in parallel and in place, round after round (a parallel
+// fixpoint of the sequential greedy).  After a few rounds almost every candidate is decided; only the
+// accepted ones and the few still-undecided ones (equal-score neighbours, long dependency chains) travel
+// to the host, which finishes with the reference's own sort + pick on that short list (pipeline.cpp).
+// state: 0 = below threshold, 1 = undecided candidate, 2 = accepted, 3 = rejected.
+__global__ __launch_bounds__(256) void k_shi_init(const double* __restrict__ score, int w, int h,
+                                                  const unsigned long long* __restrict__ max_bits, double quality,
+                                                  uint8_t* __restrict__ state) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
   const double thr = __longlong_as_double((long long)*max_bits) * quality;
-  const double s = score[(size_t)y * w + x];
-  uint8_t f = 0;
-  if (s >= thr) {
-    f = 2;
-    const int r = md - 1, md2 = md * md;
-    for (int dy = -r; dy <= r && f == 2; ++dy) {
-      const int yy = y + dy;
-      if (yy < 0 || yy >= h) continue;
-      for (int dx = -r; dx <= r; ++dx) {
-        const int xx = x + dx;
-        if (xx < 0 || xx >= w || (dx == 0 && dy == 0) || dx * dx + dy * dy >= md2) continue;
-        if (score[(size_t)yy * w + xx] >= s) { f = 1; break; }
-      }
-    }
-  }
-  flag[(size_t)y * w + x] = f;
+  state[(size_t)y * w + x] = (score[(size_t)y * w + x] >= thr) ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_shi_prune(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ flag) {
+__global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ state,
+                                                   int* __restrict__ changed) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
-  if (flag[(size_t)y * w + x] != 1) return;
+  if (state[(size_t)y * w + x] != 1) return;
   const double s = score[(size_t)y * w + x];
   const int r = md - 1, md2 = md * md;
+  bool may_be_blocked = false;  // some not-yet-rejected pixel with score >= s within min_dist
   for (int dy = -r; dy <= r; ++dy) {
     const int yy = y + dy;
     if (yy < 0 || yy >= h) continue;
     for (int dx = -r; dx <= r; ++dx) {
       const int xx = x + dx;
-      if (xx < 0 || xx >= w || dx * dx + dy * dy >= md2) continue;
-      if (flag[(size_t)yy * w + xx] == 2 && score[(size_t)yy * w + xx] > s) {
-        flag[(size_t)y * w + x] = 3;  // only 1 -> 3 transitions happen here; readers only test for 2
+      if (xx < 0 || xx >= w || (dx == 0 && dy == 0) || dx * dx + dy * dy >= md2) continue;
+      const uint8_t st = state[(size_t)yy * w + xx];
+      if (st == 0 || st == 3) continue;  // below threshold => lower score; rejected => irrelevant
+      const double sq = score[(size_t)yy * w + xx];
+      if (st == 2 && sq > s) {  // (R)
+        state[(size_t)y * w + x] = 3;
+        *changed = 1;
         return;
       }
+      if (sq >= s) may_be_blocked = true;
     }
+  }
+  if (!may_be_blocked) {  // (A)
+    state[(size_t)y * w + x] = 2;
+    *changed = 1;
   }
 }
 // ordered compaction of flag in {1,2}
@@ -394,7 +391,7 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(n * 8));
   SFMX_HIP(c, c->d[1].ensure(64));
-  SFMX_HIP(c, c->d[2].ensure((size_t)(p->h + 2) * 4 + 64));
+  SFMX_HIP(c, c->d[2].ensure((size_t)(p->h + 4) * 4 + 64));
   SFMX_HIP(c, c->d[3].ensure((size_t)cap * 4));
   SFMX_HIP(c, c->d[4].ensure((size_t)cap * 8));
   SFMX_HIP(c, c->d[5].ensure(n + 64));
@@ -405,10 +402,14 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   uint8_t* d_flag = c->d[5].as<uint8_t>();
   int rc = launch_score(c, p, c->d[0].as<double>(), d_max);
   if (rc) return rc;
-  SFMX_HIP(c, hipMemsetAsync(d_all, 0, 4, c->stream));
+  SFMX_HIP(c, hipMemsetAsync(d_all, 0, 8, c->stream));
+  int* d_changed = d_all + 1;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
-  k_shi_classify<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, min_dist, d_flag);
-  k_shi_prune<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag);
+  k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag);
+  // rounds are cheap after the first (only undecided pixels scan their neighbourhood); the fixpoint is
+  // normally reached in < 10 rounds, and stopping early is always safe (undecided pixels go to the host)
+  for (int round = 0; round < 12; ++round)
+    k_shi_round<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
   k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_all);
   k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_total);
   k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, cap, c->d[3].as<uint32_t>(), c->d[4].as<double>());

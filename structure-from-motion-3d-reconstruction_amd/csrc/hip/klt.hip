@@ -79,6 +79,23 @@ __device__ __forceinline__ void stage_windows(const uint8_t* __restrict__ img0, 
   }
 }
 
+// wave-uniform broadcast of a double held by `src` lane (v_readlane: no LDS round trip)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// hypot(sx,sy) < lim  with glibc's hypot semantics.  hypot is within a few ulp of sqrt(sx^2+sy^2), so
+// outside a 1e-9 relative band around lim^2 the squared comparison decides; inside it the exact
+// restatement is evaluated.
+__device__ __forceinline__ bool hypot_below(double sx, double sy, double lim) {
+  const double q = sx * sx + sy * sy, l2 = lim * lim;
+  if (q < l2 * (1.0 - 1e-9)) return true;
+  if (q > l2 * (1.0 + 1e-9)) return false;  // also taken for inf; NaN falls through to the exact form
+  return sfmx::hypot_glibc(sx, sy) < lim;
+}
+
 // integer part of a coordinate for window bookkeeping only (saturating; NaN -> far away)
 __device__ __forceinline__ int book_floor(double v) {
   if (!(v > -1.0e9 && v < 1.0e9)) return (int)0x40000000;
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         if (lane < 5) {
           const double2* q = reinterpret_cast<const double2*>(prod + lane * npad);
           // compile-time trip count: the LDS reads are hoisted in batches ahead of the dependent adds
-          constexpr int CH = 12;
+          constexpr int CH = 16;
 #pragma unroll
           for (int i0 = 0; i0 < npix / 2; i0 += CH) {
             double2 v[CH];
@@ -168,8 +185,8 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
           if (npix & 1) acc += prod[lane * npad + npix - 1];
         }
         __syncthreads();  // products consumed; next iteration may overwrite
-        const double A00 = __shfl(acc, 0, 64), A01 = __shfl(acc, 1, 64), A11 = __shfl(acc, 2, 64);
-        const double b0 = __shfl(acc, 3, 64), b1 = __shfl(acc, 4, 64);
+        const double A00 = readlane_f64(acc, 0), A01 = readlane_f64(acc, 1), A11 = readlane_f64(acc, 2);
+        const double b0 = readlane_f64(acc, 3), b1 = readlane_f64(acc, 4);
         // ---- 2x2 solve (T:451-459)
         double sx = 0.0, sy = 0.0;
         const double detA = A00 * A11 - A01 * A01;
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         ++steps;
         dlx += sx;
         dly += sy;
-        if (sfmx::hypot_glibc(sx, sy) < 1e-3) break;
+        if (hypot_below(sx, sy, 1e-3)) break;
       }
       px = (plx + dlx) * (double)(1 << l);
       py = (ply + dly) * (double)(1 << l);

@@ -46,7 +46,34 @@ __device__ __forceinline__ Rot half_angle(double y, double x) {
   return r;
 }
 
-__device__ __forceinline__ double shfl_xor16(double v, int o) { return __shfl_xor(v, o, HG); }
+// Same rotation without IEEE divisions / square roots: v_rsq_f64 seed + one Newton step (relative
+// error ~1e-15).  Only used for the 9x9 hypothesis Jacobi, whose E's rank hypotheses and never leave
+// the library (the winner is re-derived on the host); Jacobi is self-correcting, so the final
+// eigenvectors are as accurate as with the exact rotation.
+__device__ __forceinline__ double rsqrt_nr(double a) {
+  double r = __builtin_amdgcn_rsq(a);
+  r = r * (1.5 - 0.5 * a * r * r);
+  r = r * (1.5 - 0.5 * a * r * r);
+  return r;
+}
+__device__ __forceinline__ Rot half_angle_fast(double y, double x) {
+  Rot r;
+  const double d = y * y + x * x;
+  if (!(d > 0.0) || !(d < 1e300)) return half_angle(y, x);
+  const double rh = rsqrt_nr(d);
+  const double c2 = x * rh, s2 = y * rh;
+  if (x >= 0.0) {
+    const double u = 0.5 * (1.0 + c2), ru = rsqrt_nr(u);
+    r.c = u * ru;
+    r.s = 0.5 * s2 * ru;
+  } else {
+    const double u = 0.5 * (1.0 - c2), ru = rsqrt_nr(u);
+    const double sa = u * ru;
+    r.s = (y < 0.0) ? -sa : sa;
+    r.c = 0.5 * fabs(s2) * ru;
+  }
+  return r;
+}
 
 // serial 3x3 Jacobi (linalg.hpp:133-201, N=3) on LDS-resident A3/V3, executed by one lane
 __device__ void jacobi3_lds(double* A, double* V, int sweeps) {
@@ -195,33 +222,27 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
   }
   __syncthreads();
   // ---- 9x9 Jacobi (linalg.hpp:141-186)
+  // Every lane of the group scans the 36 upper-triangle entries itself (LDS broadcast reads, strict
+  // '>' in row-major order = the reference's first-maximum rule), so no cross-lane reduction and no
+  // index decoding sits on the per-rotation critical path.
   bool active = live;
   for (int it = 0; it < sweeps; ++it) {
-    // pivot: largest |A[i][j]|, i<j, first in row-major order (36 candidates over 16 lanes)
-    double bv = -1.0;
-    int be = 0;
+    double bv = 0.0;
+    int p = 0, q = 1;
     if (active) {
-      for (int e = t; e < 36; e += HG) {
-        int i = 0, rem = e;
-        while (rem >= 8 - i) { rem -= 8 - i; i++; }
-        const int j = i + 1 + rem;
-        const double v = fabs(L.A[i * 9 + j]);
-        if (v > bv) { bv = v; be = e; }  // NaN never wins, as in the reference's `v > maxv`
-      }
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) {
+          const double v = fabs(L.A[i * 9 + j]);
+          if (v > bv) { bv = v; p = i; q = j; }  // NaN never wins, as in the reference's `v > maxv`
+        }
     }
-    for (int o = HG / 2; o > 0; o >>= 1) {
-      const double ov = shfl_xor16(bv, o);
-      const int oe = __shfl_xor(be, o, HG);
-      if (ov > bv || (ov == bv && oe < be)) { bv = ov; be = oe; }
-    }
-    if (active && !(bv > 0.0 && !(bv < 1e-12))) active = false;  // maxv < 1e-12 -> break (incl. all-zero / all-NaN)
+    if (active && bv < 1e-12) active = false;  // maxv < 1e-12 -> break
     if (!__any(active)) break;
-    int p = 0, rem = be;
-    while (rem >= 8 - p) { rem -= 8 - p; p++; }
-    const int q = p + 1 + rem;
     Rot r;
     r.c = 1.0; r.s = 0.0;
-    if (active) r = half_angle(2.0 * L.A[p * 9 + q], L.A[q * 9 + q] - L.A[p * 9 + p]);
+    if (active) r = half_angle_fast(2.0 * L.A[p * 9 + q], L.A[q * 9 + q] - L.A[p * 9 + p]);
     const double c = r.c, s = r.s;
     __syncthreads();
     if (active && t < 9) {  // rows p,q
@@ -230,11 +251,11 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
       L.A[q * 9 + t] = s * ap + c * aq;
     }
     __syncthreads();
-    if (active && t < 9) {  // columns p,q on the row-updated matrix
+    if (active && t < 9) {  // columns p,q on the row-updated matrix, and the eigenvector columns
       const double ap = L.A[t * 9 + p], aq = L.A[t * 9 + q];
+      const double vp = L.V[t * 9 + p], vq = L.V[t * 9 + q];
       L.A[t * 9 + p] = c * ap - s * aq;
       L.A[t * 9 + q] = s * ap + c * aq;
-      const double vp = L.V[t * 9 + p], vq = L.V[t * 9 + q];
       L.V[t * 9 + p] = c * vp - s * vq;
       L.V[t * 9 + q] = s * vp + c * vq;
     }
