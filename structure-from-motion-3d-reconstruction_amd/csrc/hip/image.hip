@@ -247,35 +247,67 @@ __global__ __launch_bounds__(256) void k_shi_init(const double* __restrict__ sco
   const double thr = __longlong_as_double((long long)*max_bits) * quality;
   state[(size_t)y * w + x] = (score[(size_t)y * w + x] >= thr) ? 1 : 0;
 }
+// One round over a 64x16-pixel tile per 256-thread block.  Blocks without an undecided pixel leave
+// after one byte load per pixel; the others stage scores + states of the tile and its (min_dist-1)
+// halo in LDS once, so the 225-tap neighbourhood scans of all their undecided pixels are LDS traffic
+// (the global version of this scan was a ~50 us dependent-load chain per undecided pixel).
+#define SR_TX 64
+#define SR_TY 16
+#define SR_MAXR 15
 __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ state,
                                                    int* __restrict__ changed) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x >= w || y >= h) return;
-  if (state[(size_t)y * w + x] != 1) return;
-  const double s = score[(size_t)y * w + x];
+  extern __shared__ __align__(16) unsigned char sr_mem[];
   const int r = md - 1, md2 = md * md;
-  bool may_be_blocked = false;  // some not-yet-rejected pixel with score >= s within min_dist
-  for (int dy = -r; dy <= r; ++dy) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= h) continue;
-    for (int dx = -r; dx <= r; ++dx) {
-      const int xx = x + dx;
-      if (xx < 0 || xx >= w || (dx == 0 && dy == 0) || dx * dx + dy * dy >= md2) continue;
-      const uint8_t st = state[(size_t)yy * w + xx];
-      if (st == 0 || st == 3) continue;  // below threshold => lower score; rejected => irrelevant
-      const double sq = score[(size_t)yy * w + xx];
-      if (st == 2 && sq > s) {  // (R)
-        state[(size_t)y * w + x] = 3;
-        *changed = 1;
-        return;
+  const int lw = SR_TX + 2 * r, lh = SR_TY + 2 * r;
+  double* ts = reinterpret_cast<double*>(sr_mem);             // [lh][lw] scores
+  uint8_t* tq = reinterpret_cast<uint8_t*>(ts + (size_t)lw * lh);  // [lh][lw] states
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  const int x0 = blockIdx.x * SR_TX, y0 = blockIdx.y * SR_TY;
+  const int x = x0 + tx;
+  bool any = false;
+  uint8_t mine[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int y = y0 + ty + 4 * k;
+    mine[k] = (x < w && y < h) ? state[(size_t)y * w + x] : 0;
+    any |= (mine[k] == 1);
+  }
+  if (!__syncthreads_or(any)) return;
+  for (int i = tid; i < lw * lh; i += 256) {
+    const int ly = i / lw, lx = i % lw;
+    const int gx = x0 + lx - r, gy = y0 + ly - r;
+    const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+    ts[i] = in ? score[(size_t)gy * w + gx] : -1.0;
+    tq[i] = in ? state[(size_t)gy * w + gx] : 0;
+  }
+  __syncthreads();
+  bool ch = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (mine[k] != 1) continue;
+    const int cy = ty + 4 * k + r, cx = tx + r;
+    const double s = ts[cy * lw + cx];
+    bool may_be_blocked = false, rejected = false;
+    for (int dy = -r; dy <= r; ++dy) {
+      const int rem = md2 - dy * dy;  // dx*dx < rem
+      const double* rs = ts + (cy + dy) * lw + cx;
+      const uint8_t* rq = tq + (cy + dy) * lw + cx;
+#pragma unroll 5
+      for (int dx = -r; dx <= r; ++dx) {
+        if (dx * dx >= rem || (dx == 0 && dy == 0)) continue;
+        const uint8_t st = rq[dx];
+        const double sq = rs[dx];
+        if (st == 0 || st == 3) continue;          // below threshold / rejected: irrelevant
+        rejected |= (st == 2 && sq > s);            // (R)
+        may_be_blocked |= (sq >= s);
       }
-      if (sq >= s) may_be_blocked = true;
+      if (rejected) break;
     }
+    const int y = y0 + ty + 4 * k;
+    if (rejected) { state[(size_t)y * w + x] = 3; ch = true; }
+    else if (!may_be_blocked) { state[(size_t)y * w + x] = 2; ch = true; }  // (A)
   }
-  if (!may_be_blocked) {  // (A)
-    state[(size_t)y * w + x] = 2;
-    *changed = 1;
-  }
+  if (ch) *changed = 1;
 }
 // ordered compaction of flag in {1,2}
 __global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* __restrict__ row_count, int* __restrict__ row_all) {
@@ -386,7 +418,7 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
 
 int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap, uint32_t* cand_xy,
                                       double* cand_score, int* n_out, int* n_total_out, double* max_out) {
-  SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 32768 && p->h < 32768 && min_dist >= 1 && min_dist <= 64);
+  SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 32768 && p->h < 32768 && min_dist >= 1 && min_dist <= SR_MAXR + 1);
   const size_t n = (size_t)p->w * p->h;
   c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(n * 8));
@@ -406,10 +438,22 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   int* d_changed = d_all + 1;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag);
-  // rounds are cheap after the first (only undecided pixels scan their neighbourhood); the fixpoint is
-  // normally reached in < 10 rounds, and stopping early is always safe (undecided pixels go to the host)
-  for (int round = 0; round < 12; ++round)
-    k_shi_round<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
+  // Rounds until nothing changes (checked every 3 rounds; stopping early would also be safe: undecided
+  // pixels simply travel to the host).  The fixpoint is normally reached in 6-9 rounds.
+  {
+    const int r = min_dist - 1;
+    const size_t shm = (size_t)(SR_TX + 2 * r) * (SR_TY + 2 * r) * 9 + 16;
+    dim3 gt((p->w + SR_TX - 1) / SR_TX, (p->h + SR_TY - 1) / SR_TY);
+    for (int batch = 0; batch < 8; ++batch) {
+      SFMX_HIP(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
+      for (int k = 0; k < 3; ++k) k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
+      SFMX_HIP(c, hipGetLastError());
+      int changed = 0;
+      SFMX_HIP(c, hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
+      SFMX_HIP(c, hipStreamSynchronize(c->stream));
+      if (!changed) break;
+    }
+  }
   k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_all);
   k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_total);
   k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, cap, c->d[3].as<uint32_t>(), c->d[4].as<double>());

@@ -78,13 +78,13 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
 
   static const bool force_full = std::getenv("SFMX_SHI_FULL_SORT") != nullptr;  // test hook: always take the exact slow path
   bool done = false;
-  if (!force_full && min_dist >= 1 && min_dist <= 64) {
+  if (!force_full && min_dist >= 1 && min_dist <= 16) {
     // ---- fast path: the device has already removed every candidate that is certainly rejected
     int n = 0, n_total = 0;
     double maxv = 0;
     check(ctx_, sfmx_shi_tomasi_candidates_pruned(ctx_, pyr, quality, min_dist, cap, cand_xy_.data(), cand_s_.data(), &n, &n_total, &maxv),
           "shi_tomasi_candidates_pruned");
-    if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
+    if (clk_) { clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_); clk_->shi_gpu += since(t0); }
     std::vector<Cand> cands((size_t)n);
     for (int i = 0; i < n; i++)
       cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0x7fffu), (int)((cand_xy_[(size_t)i] >> 16) & 0x7fffu), cand_s_[(size_t)i], i};
@@ -119,6 +119,7 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
     if (ambiguous) {
       // ---- tie order from a selective replay of libstdc++'s introsort on the FULL candidate list
       if (clk_) clk_->shi_fallbacks++;
+      const auto tr0 = Clock::now();
       std::vector<std::uint32_t> sel_xy((size_t)n);
       for (int k = 0; k < n; k++) sel_xy[(size_t)k] = cand_xy_[(size_t)k] & 0x7fff7fffu;  // pruned list, row-major order
       std::vector<Cand> pruned((size_t)n);
@@ -160,6 +161,7 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
         }
         done = true;
       }
+      if (clk_) clk_->shi_replay += since(tr0);
     }
   }
   if (!done) {
@@ -601,7 +603,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       kf.frame_idx = fi;
       kf.img_name = meta[(size_t)fi].name;
       kf.pose = cur;
+      const auto td0 = Clock::now();
       const auto new_desc = global_desc_32(ctx, tracker.current(), dlevel);
+      clk.desc += since(td0);
+      const auto tb0 = Clock::now();
       for (const Track& tr : tracker.tracks()) {
         kf.obs.emplace(tr.id, tr.p);
         track_hist[tr.id].push_back({kf.kf_id, tr.p});
@@ -618,6 +623,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           ei.push_back(itp->second);
           ej.push_back(kv.second);
         }
+        clk.bookkeeping += since(tb0);
         if (ei.size() >= 80) {
           auto eopt = find_E_ransac_gpu(ctx, K, ei, ej, 2500, 1e-3, 60, &clk);
           if (eopt) edges.push_back(PGEdge{prev_kf.kf_id, kf.kf_id, eopt->R_ji, eopt->t_ji, (int)eopt->inliers.size(), false});
@@ -747,7 +753,7 @@ struct sfmx_pipeline_cfg {
 };
 struct sfmx_pipeline_stats {
   int n_keyframes, n_points, n_edges, n_frames;
-  double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host;
+  double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host, sec_shi_gpu, sec_shi_replay, sec_desc, sec_bookkeeping;
   double us_klt_kernel, us_ransac_kernel, us_ba_kernel, us_shi_kernel;
   unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks;
 };
@@ -790,7 +796,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     if (stats) {
       const StageClock& c = res.clock;
       *stats = sfmx_pipeline_stats{(int)res.kfs.size(), (int)res.map.pts.size(), (int)res.edges.size(), std::min(pc.frames, n_images),
-                                   c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host,
+                                   c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host, c.shi_gpu, c.shi_replay, c.desc, c.bookkeeping,
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
                                    c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks};
     }

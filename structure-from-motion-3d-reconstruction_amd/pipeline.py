@@ -25,6 +25,7 @@ class PipelineStats(ctypes.Structure):
     _fields_ = [("n_keyframes", c_int), ("n_points", c_int), ("n_edges", c_int), ("n_frames", c_int),
                 ("sec_total", c_double), ("sec_klt", c_double), ("sec_shi", c_double), ("sec_ransac", c_double),
                 ("sec_ba", c_double), ("sec_upload", c_double), ("sec_host", c_double),
+                ("sec_shi_gpu", c_double), ("sec_shi_replay", c_double), ("sec_desc", c_double), ("sec_bookkeeping", c_double),
                 ("us_klt_kernel", c_double), ("us_ransac_kernel", c_double), ("us_ba_kernel", c_double),
                 ("us_shi_kernel", c_double),
                 ("lk_steps", c_ulonglong), ("tracks_in", c_ulonglong), ("klt_calls", c_ulonglong),
