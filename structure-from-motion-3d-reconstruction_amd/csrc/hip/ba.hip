@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const d
 // Ordered column sums: one lane per element of S / b walks the contribution rows in point order.
 // Loads of neighbouring lanes are contiguous (coalesced) and independent of the add chain, so they
 // are issued BA_AHEAD points ahead; the dependent FP64 adds are the only serial part.
-#define BA_AHEAD 16
+#define BA_AHEAD 32
 __global__ __launch_bounds__(64) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
                                                   double* __restrict__ b) {
   const int D = 6 * W, CS = ba_row_stride(W);

@@ -247,67 +247,53 @@ __global__ __launch_bounds__(256) void k_shi_init(const double* __restrict__ sco
   const double thr = __longlong_as_double((long long)*max_bits) * quality;
   state[(size_t)y * w + x] = (score[(size_t)y * w + x] >= thr) ? 1 : 0;
 }
-// One round over a 64x16-pixel tile per 256-thread block.  Blocks without an undecided pixel leave
+// One round over a 64x4-pixel tile per 256-thread block (one pixel per thread, ~1200 blocks for VGA so
+// that ~19 waves per CU hide the LDS latency of the tap loop).  Blocks without an undecided pixel leave
 // after one byte load per pixel; the others stage scores + states of the tile and its (min_dist-1)
-// halo in LDS once, so the 225-tap neighbourhood scans of all their undecided pixels are LDS traffic
-// (the global version of this scan was a ~50 us dependent-load chain per undecided pixel).
+// halo in LDS once, so the neighbourhood scans are LDS traffic (the global-memory version of this scan
+// was a ~50 us dependent-load chain per undecided pixel).
 #define SR_TX 64
-#define SR_TY 16
+#define SR_TY 4
 #define SR_MAXR 15
 __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ state,
                                                    int* __restrict__ changed) {
   extern __shared__ __align__(16) unsigned char sr_mem[];
   const int r = md - 1, md2 = md * md;
   const int lw = SR_TX + 2 * r, lh = SR_TY + 2 * r;
-  double* ts = reinterpret_cast<double*>(sr_mem);             // [lh][lw] scores
+  double* ts = reinterpret_cast<double*>(sr_mem);                  // [lh][lw] scores
   uint8_t* tq = reinterpret_cast<uint8_t*>(ts + (size_t)lw * lh);  // [lh][lw] states
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
   const int x0 = blockIdx.x * SR_TX, y0 = blockIdx.y * SR_TY;
-  const int x = x0 + tx;
-  bool any = false;
-  uint8_t mine[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int y = y0 + ty + 4 * k;
-    mine[k] = (x < w && y < h) ? state[(size_t)y * w + x] : 0;
-    any |= (mine[k] == 1);
-  }
-  if (!__syncthreads_or(any)) return;
+  const int x = x0 + tx, y = y0 + ty;
+  const uint8_t mine = (x < w && y < h) ? state[(size_t)y * w + x] : 0;
+  if (!__syncthreads_or(mine == 1)) return;
   for (int i = tid; i < lw * lh; i += 256) {
-    const int ly = i / lw, lx = i % lw;
+    const int ly = i / lw, lx = i - ly * lw;
     const int gx = x0 + lx - r, gy = y0 + ly - r;
     const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
     ts[i] = in ? score[(size_t)gy * w + gx] : -1.0;
     tq[i] = in ? state[(size_t)gy * w + gx] : 0;
   }
   __syncthreads();
-  bool ch = false;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (mine[k] != 1) continue;
-    const int cy = ty + 4 * k + r, cx = tx + r;
-    const double s = ts[cy * lw + cx];
-    bool may_be_blocked = false, rejected = false;
-    for (int dy = -r; dy <= r; ++dy) {
-      const int rem = md2 - dy * dy;  // dx*dx < rem
-      const double* rs = ts + (cy + dy) * lw + cx;
-      const uint8_t* rq = tq + (cy + dy) * lw + cx;
+  if (mine != 1) return;
+  const int cy = ty + r, cx = tx + r;
+  const double s = ts[cy * lw + cx];
+  bool may_be_blocked = false, rejected = false;
+  for (int dy = -r; dy <= r && !rejected; ++dy) {
+    const int rem = md2 - dy * dy;  // dx*dx < rem
+    const double* rs = ts + (cy + dy) * lw + cx;
+    const uint8_t* rq = tq + (cy + dy) * lw + cx;
 #pragma unroll 5
-      for (int dx = -r; dx <= r; ++dx) {
-        if (dx * dx >= rem || (dx == 0 && dy == 0)) continue;
-        const uint8_t st = rq[dx];
-        const double sq = rs[dx];
-        if (st == 0 || st == 3) continue;          // below threshold / rejected: irrelevant
-        rejected |= (st == 2 && sq > s);            // (R)
-        may_be_blocked |= (sq >= s);
-      }
-      if (rejected) break;
+    for (int dx = -r; dx <= r; ++dx) {
+      const uint8_t st = rq[dx];
+      const double sq = rs[dx];
+      const bool rel = (dx * dx < rem) && !(dx == 0 && dy == 0) && (st == 1 || st == 2);
+      rejected |= rel && (st == 2) && (sq > s);  // (R)
+      may_be_blocked |= rel && (sq >= s);
     }
-    const int y = y0 + ty + 4 * k;
-    if (rejected) { state[(size_t)y * w + x] = 3; ch = true; }
-    else if (!may_be_blocked) { state[(size_t)y * w + x] = 2; ch = true; }  // (A)
   }
-  if (ch) *changed = 1;
+  if (rejected) { state[(size_t)y * w + x] = 3; *changed = 1; }
+  else if (!may_be_blocked) { state[(size_t)y * w + x] = 2; *changed = 1; }  // (A)
 }
 // ordered compaction of flag in {1,2}
 __global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* __restrict__ row_count, int* __restrict__ row_all) {
@@ -406,10 +392,14 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   KernelTimer(c).collect();
   const int m = total < cap ? total : cap;
-  if (m > 0) {
-    SFMX_HIP(c, hipMemcpyAsync(cand_xy, c->d[3].p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-    SFMX_HIP(c, hipMemcpyAsync(cand_score, c->d[4].p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
+  if (m > 0) {  // large (MB-sized) download: through pinned staging, pageable D2H is several times slower
+    SFMX_HIP(c, c->h[0].ensure((size_t)m * 4));
+    SFMX_HIP(c, c->h[1].ensure((size_t)m * 8));
+    SFMX_HIP(c, hipMemcpyAsync(c->h[0].p, c->d[3].p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, c->d[4].p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
     SFMX_HIP(c, hipStreamSynchronize(c->stream));
+    memcpy(cand_xy, c->h[0].p, (size_t)m * 4);
+    memcpy(cand_score, c->h[1].p, (size_t)m * 8);
   }
   *n_out = total;
   if (max_out) *max_out = mx;

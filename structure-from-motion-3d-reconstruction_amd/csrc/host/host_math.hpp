@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace sfmx_host {
@@ -317,8 +318,9 @@ inline bool triangulate_dlt(const Mat3& K, const Pose& pi, const Pose& pj, V2 ui
 }
 
 // E -> (R,t) with the 4-candidate cheirality vote on the first min(20,n) inliers (T:680-760)
+using ParallelFor = std::function<void(int, const std::function<void(int)>&)>;
 inline void decompose_E(const Mat3& E, const double* xi, const double* xj, const std::vector<int>& inl, Mat3& R_out, V3& t_out,
-                        int* cand_out = nullptr) {
+                        int* cand_out = nullptr, const ParallelFor& par = nullptr) {
   const Svd d = svd3(E);
   Mat3 W;
   W(0, 1) = -1; W(1, 0) = 1; W(2, 2) = 1;
@@ -330,22 +332,31 @@ inline void decompose_E(const Mat3& E, const double* xi, const double* xj, const
   const V3 t = unit(V3{d.U(0, 2), d.U(1, 2), d.U(2, 2)});
   const Mat3 Rc[4] = {R1, R1, R2, R2};
   const V3 tc[4] = {t, V3{-t.x, -t.y, -t.z}, t, V3{-t.x, -t.y, -t.z}};
+  // 4 candidates x min(20,n) independent DLT solves; `par` (optional) runs them on a pool.  The vote is
+  // a sum of 0/1 flags, so the result does not depend on the execution order.
+  const int M = std::min((int)inl.size(), 20);
+  std::vector<unsigned char> pass((size_t)4 * (size_t)std::max(M, 1), 0);
+  auto one = [&](int job) {
+    const int c = job / M, k = job % M;
+    const int i = inl[(size_t)k];
+    const V2 a{xi[2 * i], xi[2 * i + 1]}, b{xj[2 * i], xj[2 * i + 1]};
+    const Mat3& R = Rc[c];
+    const V3& tt = tc[c];
+    const double A[16] = {-1, 0, a.x, 0, 0, -1, a.y, 0,
+                          b.x * R(2, 0) - R(0, 0), b.x * R(2, 1) - R(0, 1), b.x * R(2, 2) - R(0, 2), b.x * tt.z - tt.x,
+                          b.y * R(2, 0) - R(1, 0), b.y * R(2, 1) - R(1, 1), b.y * R(2, 2) - R(1, 2), b.y * tt.z - tt.y};
+    const V3 X = dlt_solve(A);
+    const V3 X2 = (R * X) + tt;
+    pass[(size_t)job] = (X.z > 0 && X2.z > 0) ? 1 : 0;
+  };
+  if (M > 0) {
+    if (par) par(4 * M, one);
+    else for (int job = 0; job < 4 * M; job++) one(job);
+  }
   int best = 0, bestok = -1;
   for (int c = 0; c < 4; c++) {
     int ok = 0;
-    const int M = std::min((int)inl.size(), 20);
-    for (int k = 0; k < M; k++) {
-      const int i = inl[(size_t)k];
-      const V2 a{xi[2 * i], xi[2 * i + 1]}, b{xj[2 * i], xj[2 * i + 1]};
-      const Mat3& R = Rc[c];
-      const V3& tt = tc[c];
-      const double A[16] = {-1, 0, a.x, 0, 0, -1, a.y, 0,
-                            b.x * R(2, 0) - R(0, 0), b.x * R(2, 1) - R(0, 1), b.x * R(2, 2) - R(0, 2), b.x * tt.z - tt.x,
-                            b.y * R(2, 0) - R(1, 0), b.y * R(2, 1) - R(1, 1), b.y * R(2, 2) - R(1, 2), b.y * tt.z - tt.y};
-      const V3 X = dlt_solve(A);
-      const V3 X2 = (R * X) + tt;
-      if (X.z > 0 && X2.z > 0) ok++;
-    }
+    for (int k = 0; k < M; k++) ok += pass[(size_t)(c * M + k)];
     if (ok > bestok) { bestok = ok; best = c; }
   }
   R_out = Rc[best];

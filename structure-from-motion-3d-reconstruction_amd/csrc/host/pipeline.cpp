@@ -3,6 +3,7 @@
 
 #include "../hip/sfmx_math.h"
 #include "introsort_replay.hpp"
+#include "thread_pool.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -298,8 +299,33 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
   // the reference draws 8 indices per iteration from mt19937(12345) (T:657-665); pre-draw the stream
   std::vector<std::int32_t> idx8((size_t)8 * std::max(iters, 0));
   {
-    Mt19937 rng(12345);
-    for (size_t k = 0; k < idx8.size(); k++) idx8[k] = rng.below((std::uint32_t)n);
+    // The generator is re-seeded with 12345 on every call, so its raw 32-bit output stream is the same
+    // every time; only the range reduction depends on n.  Cache the raw stream; a Lemire rejection
+    // (probability < n / 2^32 per draw) consumes one extra raw value exactly as libstdc++ does.
+    static thread_local std::vector<std::uint32_t> raw;
+    const size_t want = idx8.size() + 64;
+    if (raw.size() < want) {
+      Mt19937 rng(12345);
+      raw.resize(std::max(want, (size_t)8 * 4096 + 64));
+      for (auto& v : raw) v = rng.next();
+    }
+    size_t pos = 0;
+    bool exhausted = false;
+    const std::uint32_t range = (std::uint32_t)n;
+    const std::uint32_t thr = (0u - range) % range;
+    for (size_t k = 0; k < idx8.size() && !exhausted; k++) {
+      std::uint64_t prod = (std::uint64_t)raw[pos++] * range;
+      while ((std::uint32_t)prod < thr) {
+        if (pos >= raw.size()) { exhausted = true; break; }
+        prod = (std::uint64_t)raw[pos++] * range;
+      }
+      idx8[k] = (std::int32_t)(prod >> 32);
+      if (pos >= raw.size() && k + 1 < idx8.size()) exhausted = true;
+    }
+    if (exhausted) {  // more rejections than the 64-value margin: regenerate the plain way
+      Mt19937 rng(12345);
+      for (size_t k = 0; k < idx8.size(); k++) idx8[k] = rng.below(range);
+    }
   }
   if (iters <= 0) return std::nullopt;
   std::vector<std::int32_t> counts((size_t)iters);
@@ -360,7 +386,8 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
       rp.best_iter = win_iter;
       for (int i = 0; i < n; i++)
         if (win_mask[(size_t)i]) rp.inliers.push_back(i);
-      decompose_E(winE, xi.data(), xj.data(), rp.inliers, rp.R_ji, rp.t_ji);
+      decompose_E(winE, xi.data(), xj.data(), rp.inliers, rp.R_ji, rp.t_ji, nullptr,
+                  [](int n, const std::function<void(int)>& f) { ThreadPool::instance().parallel_for(n, f, 8); });
       result = std::move(rp);
     }
   }
@@ -631,6 +658,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       }
       if (kfs.size() >= 1) {  // triangulate new points (T:1801-1813)
         const auto th0 = Clock::now();
+        // The DLT solves (libm Jacobi) are independent: gather the jobs in the reference's iteration
+        // order, solve them on the host pool, then insert into the map sequentially in that same order.
+        struct TriJob { int tid; const std::vector<std::pair<int, V2>>* hist; const Pose* p0; const Pose* pl; V3 X; bool ok; };
+        std::vector<TriJob> jobs;
         for (auto& kv : track_hist) {
           const int tid = kv.first;
           auto& hist = kv.second;
@@ -641,11 +672,17 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           // construction is pushed (T:1815), i.e. one past the end of the vector whenever idl is the
           // new keyframe — undefined behaviour whose result is heap garbage.  The defined reading is
           // used here: the new keyframe's own pose.
-          const Pose& pl = (idl < (int)kfs.size()) ? kfs[(size_t)idl].pose : kf.pose;
-          V3 Xw;
-          if (!triangulate_dlt(K, kfs[(size_t)id0].pose, pl, hist.front().second, hist.back().second, Xw)) throw std::runtime_error("Singular K");
-          map.add(tid, Xw);
-          for (const auto& ob : hist) map.add_obs(tid, ob.first, ob.second);
+          const Pose* pl = (idl < (int)kfs.size()) ? &kfs[(size_t)idl].pose : &kf.pose;
+          jobs.push_back(TriJob{tid, &hist, &kfs[(size_t)id0].pose, pl, V3{}, true});
+        }
+        ThreadPool::instance().parallel_for((int)jobs.size(), [&](int i) {
+          TriJob& j = jobs[(size_t)i];
+          j.ok = triangulate_dlt(K, *j.p0, *j.pl, j.hist->front().second, j.hist->back().second, j.X);
+        });
+        for (const TriJob& j : jobs) {
+          if (!j.ok) throw std::runtime_error("Singular K");
+          map.add(j.tid, j.X);
+          for (const auto& ob : *j.hist) map.add_obs(j.tid, ob.first, ob.second);
         }
         clk.host += since(th0);
       }
