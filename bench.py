@@ -188,8 +188,19 @@ def main():
             kname = "k_shi_score"
         ach_gbs = alg_bytes / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
         ach_tf = alg_flop / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
+        # HBM traffic per launch of that kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
+        # tools/prof_kernels.py at the same sizes; FETCH_SIZE/WRITE_SIZE are KB; byte-granular loads are
+        # uncalibrated on gfx950 -- MI355X_MICROARCH.md §HBM -- so the raw counter sum is reported)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            for row in pmc:
+                if row["kernel"].replace("void ", "").startswith(kname.split("+")[0]):
+                    traffic = int((row.get("FETCH_SIZE_avg", 0.0) + row.get("WRITE_SIZE_avg", 0.0)) * 1024)
+        except Exception:
+            traffic = None
         roofline = dict(bound="hbm", achieved=round(ach_gbs, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gbs / HBM_PEAK_GBS, 6),
-                        traffic=None, kernel=kname, avg_launch_us=round(avg_us, 2), launches_per_pass=int(launches),
+                        traffic=traffic, kernel=kname, avg_launch_us=round(avg_us, 2), launches_per_pass=int(launches),
                         algorithmic_bytes_per_launch=int(alg_bytes),
                         note="path is FP64-VALU/latency bound, not HBM bound (SURVEY.md §8d); see fp64_valu",
                         fp64_valu=dict(achieved=round(ach_tf, 4), peak=FP64_VALU_PEAK_TF, unit="TFLOP/s", frac=round(ach_tf / FP64_VALU_PEAK_TF, 5)),
@@ -206,7 +217,7 @@ def main():
                                    "one independent sequence per GPU", "frames_per_step": args.frames, "parallelism": f"sequences x{world}"},
             "frames_per_s": round(args.frames * args.steps * world / dt, 2),
             "keyframes_per_step": st["n_keyframes"], "map_points": st["n_points"],
-            "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_total", "sec_klt", "sec_shi", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping")},
+            "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_total", "sec_klt", "sec_shi", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert")},
             "counters_per_step": {k: int(st[k]) for k in ("klt_calls", "tracks_in", "lk_steps", "ransac_calls", "ransac_points", "ransac_verified", "ba_calls", "ba_iters", "shi_fallbacks")},
             "roofline": roofline,
         }

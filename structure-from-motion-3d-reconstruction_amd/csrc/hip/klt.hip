@@ -24,7 +24,12 @@
 #include "sfmx_internal.h"
 
 #define KLT_P 32          // staged window is KLT_P x KLT_P pixels
-#define KLT_PS 33         // LDS row stride (floats)
+// LDS row stride (floats) of the staged windows.  Lane l owns window pixel l = (dy+r)*(2r+1)+(dx+r)
+// and reads win[(y0+dy)*PS + x0+dx]; with PS = 32 + (2r+1) the bank (address mod 32) of that read is
+// l + const, so 32 consecutive lanes hit 32 distinct banks.  (Stride 33 put every anti-diagonal of
+// the 11x11 window on one bank: rocprofv3 showed 2.6 conflict cycles per LDS instruction.)
+#define KLT_PS_FOR(r) (32 + 2 * (r) + 1)
+#define KLT_PS_MAX KLT_PS_FOR(KLT_MAX_R)
 #define KLT_MAX_R 7
 #define KLT_MAX_NPIX ((2 * KLT_MAX_R + 1) * (2 * KLT_MAX_R + 1))
 
@@ -41,6 +46,7 @@ __device__ __forceinline__ Tap make_tap(double v, int extent) {
   return t;
 }
 // T:183-198 on the staged window (ox,oy = window origin in image coordinates)
+template <int KLT_PS>
 __device__ __forceinline__ double sample_lds(const float* __restrict__ win, int ox, int oy, const Tap& cx, const Tap& cy) {
   if (!(cx.ok && cy.ok)) return 0.0;
   int lx = cx.i0 - ox, ly = cy.i0 - oy;
@@ -55,6 +61,7 @@ __device__ __forceinline__ double sample_lds(const float* __restrict__ win, int 
 
 // Both windows are staged together: all 32 byte loads of a lane are issued before the first LDS
 // store, so one staging costs about one L2 round trip instead of 32 dependent ones.
+template <int KLT_PS>
 __device__ __forceinline__ void stage_windows(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int w, int h, int ox,
                                               int oy, float* __restrict__ win0, float* __restrict__ win1, int lane) {
   constexpr int N = KLT_P * KLT_P / 64;  // 16 pixels per lane per image
@@ -109,13 +116,14 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
                                                   unsigned long long* __restrict__ step_counter) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* win0 = reinterpret_cast<float*>(smem);                 // template image window (I0 of lk_step)
-  float* win1 = win0 + KLT_P * KLT_PS;                          // current image window  (I1 of lk_step)
-  double* prod = reinterpret_cast<double*>(win1 + KLT_P * KLT_PS);      // [5][npix_pad], 16-B aligned
+  float* win1 = win0 + KLT_P * KLT_PS_FOR(r);                   // current image window  (I1 of lk_step)
+  double* prod = reinterpret_cast<double*>(win0 + ((2 * KLT_P * KLT_PS_FOR(r) + 3) & ~3));  // [5][npix_pad], 16-B aligned
   const int lane = threadIdx.x;
   const int track = blockIdx.x;
   if (track >= n) return;
   constexpr int side = 2 * r + 1, npix = side * side;
   constexpr int npad = (npix + 1) & ~1;
+  constexpr int KLT_PS = KLT_PS_FOR(r);
 
   const double p0x = xy_in[2 * track], p0y = xy_in[2 * track + 1];
   double px = p0x, py = p0y;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
             ox = bx - (KLT_P / 2 - 1);
             oy = by - (KLT_P / 2 - 1);
             __syncthreads();
-            stage_windows(img0, img1, w, h, ox, oy, win0, win1, lane);
+            stage_windows<KLT_PS>(img0, img1, w, h, ox, oy, win0, win1, lane);
             __syncthreads();
           }
         }
@@ -154,10 +162,10 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
           const double xx = x + (double)dxi, yy = y + (double)dyi;
           const Tap cx0 = make_tap(xx, w), cxp = make_tap(xx + 1, w), cxm = make_tap(xx - 1, w);
           const Tap cy0 = make_tap(yy, h), cyp = make_tap(yy + 1, h), cym = make_tap(yy - 1, h);
-          const double Ix = 0.5 * (sample_lds(win1, ox, oy, cxp, cy0) - sample_lds(win1, ox, oy, cxm, cy0));
-          const double Iy = 0.5 * (sample_lds(win1, ox, oy, cx0, cyp) - sample_lds(win1, ox, oy, cx0, cym));
-          const double Iref = sample_lds(win0, ox, oy, cx0, cy0);
-          const double Icur = sample_lds(win1, ox, oy, cx0, cy0);
+          const double Ix = 0.5 * (sample_lds<KLT_PS>(win1, ox, oy, cxp, cy0) - sample_lds<KLT_PS>(win1, ox, oy, cxm, cy0));
+          const double Iy = 0.5 * (sample_lds<KLT_PS>(win1, ox, oy, cx0, cyp) - sample_lds<KLT_PS>(win1, ox, oy, cx0, cym));
+          const double Iref = sample_lds<KLT_PS>(win0, ox, oy, cx0, cy0);
+          const double Icur = sample_lds<KLT_PS>(win1, ox, oy, cx0, cy0);
           const double err = Iref - Icur;
           prod[0 * npad + pix] = Ix * Ix;
           prod[1 * npad + pix] = Ix * Iy;
@@ -237,7 +245,7 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xy_in, nb, hipMemcpyHostToDevice, c->stream));
   SFMX_HIP(c, hipMemsetAsync(c->d[4].p, 0, 8, c->stream));
   const int r = cfg->win_radius, npix = (2 * r + 1) * (2 * r + 1), npad = (npix + 1) & ~1;
-  const size_t shmem = (size_t)(2 * KLT_P * KLT_PS) * sizeof(float) + (size_t)5 * npad * sizeof(double);
+  const size_t shmem = (size_t)((2 * KLT_P * KLT_PS_FOR(r) + 3) & ~3) * sizeof(float) + (size_t)5 * npad * sizeof(double);
   KernelTimer t(c);
   t.start();
 #define KLT_LAUNCH(RR)                                                                                                          \

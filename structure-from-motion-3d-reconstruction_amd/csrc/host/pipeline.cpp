@@ -328,6 +328,8 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
     }
   }
   if (iters <= 0) return std::nullopt;
+  if (clk) clk->r_pre += since(t0);
+  const auto tg0 = Clock::now();
   std::vector<std::int32_t> counts((size_t)iters);
   std::int32_t best_iter = -1, best_count = 0;
   check(ctx, sfmx_ransac_score(ctx, xi.data(), xj.data(), n, idx8.data(), iters, thr, counts.data(), &best_iter, &best_count, nullptr),
@@ -336,7 +338,9 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
     clk->ransac_kernel_us += sfmx_last_kernel_us(ctx);
     clk->ransac_calls++;
     clk->ransac_points += (std::uint64_t)n;
+    clk->r_gpu += since(tg0);
   }
+  const auto tv0 = Clock::now();
   // Device hypotheses rank the iterations; the winner's E is re-derived with the platform libm (so it
   // is the reference's E bit for bit) and its mask recomputed from that E on the device.
   //
@@ -381,6 +385,8 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
         for (int it : near)
           if (it > best_iter) verify(it);
     }
+    if (clk) clk->r_verify += since(tv0);
+    const auto td0 = Clock::now();
     if (win_iter >= 0 && win_count >= min_inliers) {  // T:678
       RelPose rp;
       rp.best_iter = win_iter;
@@ -390,6 +396,7 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
                   [](int n, const std::function<void(int)>& f) { ThreadPool::instance().parallel_for(n, f, 8); });
       result = std::move(rp);
     }
+    if (clk) clk->r_decomp += since(td0);
   }
   if (clk) clk->ransac += since(t0);
   return result;
@@ -675,15 +682,20 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           const Pose* pl = (idl < (int)kfs.size()) ? &kfs[(size_t)idl].pose : &kf.pose;
           jobs.push_back(TriJob{tid, &hist, &kfs[(size_t)id0].pose, pl, V3{}, true});
         }
+        clk.tri_iter += since(th0);
+        const auto ts0 = Clock::now();
         ThreadPool::instance().parallel_for((int)jobs.size(), [&](int i) {
           TriJob& j = jobs[(size_t)i];
           j.ok = triangulate_dlt(K, *j.p0, *j.pl, j.hist->front().second, j.hist->back().second, j.X);
         });
+        clk.tri_solve += since(ts0);
+        const auto ti0 = Clock::now();
         for (const TriJob& j : jobs) {
           if (!j.ok) throw std::runtime_error("Singular K");
           map.add(j.tid, j.X);
           for (const auto& ob : *j.hist) map.add_obs(j.tid, ob.first, ob.second);
         }
+        clk.tri_insert += since(ti0);
         clk.host += since(th0);
       }
       kfs.push_back(std::move(kf));
@@ -790,7 +802,7 @@ struct sfmx_pipeline_cfg {
 };
 struct sfmx_pipeline_stats {
   int n_keyframes, n_points, n_edges, n_frames;
-  double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host, sec_shi_gpu, sec_shi_replay, sec_desc, sec_bookkeeping;
+  double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host, sec_shi_gpu, sec_shi_replay, sec_desc, sec_bookkeeping, sec_r_pre, sec_r_gpu, sec_r_verify, sec_r_decomp, sec_tri_iter, sec_tri_solve, sec_tri_insert;
   double us_klt_kernel, us_ransac_kernel, us_ba_kernel, us_shi_kernel;
   unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks;
 };
@@ -833,7 +845,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     if (stats) {
       const StageClock& c = res.clock;
       *stats = sfmx_pipeline_stats{(int)res.kfs.size(), (int)res.map.pts.size(), (int)res.edges.size(), std::min(pc.frames, n_images),
-                                   c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host, c.shi_gpu, c.shi_replay, c.desc, c.bookkeeping,
+                                   c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host, c.shi_gpu, c.shi_replay, c.desc, c.bookkeeping, c.r_pre, c.r_gpu, c.r_verify, c.r_decomp, c.tri_iter, c.tri_solve, c.tri_insert,
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
                                    c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks};
     }

@@ -57,6 +57,7 @@ struct MemoryFrames : FrameSource {
 
 struct StageClock {
   double klt = 0, shi = 0, ransac = 0, ba = 0, upload = 0, host = 0, total = 0, shi_gpu = 0, shi_replay = 0, desc = 0, bookkeeping = 0;
+  double r_pre = 0, r_gpu = 0, r_verify = 0, r_decomp = 0, tri_iter = 0, tri_solve = 0, tri_insert = 0;
   double klt_kernel_us = 0, ransac_kernel_us = 0, ba_kernel_us = 0, shi_kernel_us = 0;
   std::uint64_t lk_steps = 0, tracks_in = 0, ransac_calls = 0, ransac_points = 0, ba_calls = 0, ba_iters = 0, klt_calls = 0;
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0;

@@ -26,6 +26,8 @@ class PipelineStats(ctypes.Structure):
                 ("sec_total", c_double), ("sec_klt", c_double), ("sec_shi", c_double), ("sec_ransac", c_double),
                 ("sec_ba", c_double), ("sec_upload", c_double), ("sec_host", c_double),
                 ("sec_shi_gpu", c_double), ("sec_shi_replay", c_double), ("sec_desc", c_double), ("sec_bookkeeping", c_double),
+                ("sec_r_pre", c_double), ("sec_r_gpu", c_double), ("sec_r_verify", c_double), ("sec_r_decomp", c_double),
+                ("sec_tri_iter", c_double), ("sec_tri_solve", c_double), ("sec_tri_insert", c_double),
                 ("us_klt_kernel", c_double), ("us_ransac_kernel", c_double), ("us_ba_kernel", c_double),
                 ("us_shi_kernel", c_double),
                 ("lk_steps", c_ulonglong), ("tracks_in", c_ulonglong), ("klt_calls", c_ulonglong),

@@ -258,3 +258,30 @@ def test_solve_dense(ctx, golden):
     erc, ex = H.solve_gauss(O, "orc", A, np.ones(9))
     assert rc == erc == 0
     H.assert_bits_equal(x, ex, "nan solve", nan_equal=True)
+
+
+def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
+    """dist.ba_step_sharded (partial build -> [all-reduce] -> damp/gauge -> solve) on one rank must equal the fused
+    sfmx_ba_step bit for bit: same sums, no collective reordering with world size 1."""
+    import torch
+    dist_mod = importlib.import_module(H.PKG_NAME + ".dist")
+    rng = np.random.default_rng(8)
+    W, P = 4, 50
+    pw = np.zeros((W, 12))
+    for k in range(W):
+        R, t = synth.ring_pose(3.0 * k)
+        pw[k, :9], pw[k, 9:] = R.ravel(), t
+    K = synth.K_TEMPLE
+    X = rng.normal(size=(P, 3)) * 0.05
+    ptr = np.arange(0, (P + 1) * W, W, dtype=np.int32)
+    li = np.tile(np.arange(W, dtype=np.int32), P)
+    uv = np.zeros((P * W, 2))
+    for p in range(P):
+        for k in range(W):
+            Xc = pw[k, :9].reshape(3, 3) @ X[p] + pw[k, 9:]
+            uv[p * W + k] = [K[0, 0] * Xc[0] / Xc[2] + K[0, 2] + rng.normal(), K[1, 1] * Xc[1] / Xc[2] + K[1, 2] + rng.normal()]
+    prob = ctx.ba_problem(W, X, ptr, li, uv)
+    rc1, dx1 = prob.step(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    rc2, dx2 = dist_mod.ba_step_sharded(ctx, prob, pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, torch.device("cuda:0"))
+    assert rc1 == rc2 == 0
+    H.assert_bits_equal(dx1, dx2, "sharded vs fused dx")
