@@ -76,8 +76,11 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double qu
  * certainly accepted ones, the rest are still undecided; x = bits 0..14, y = bits 16..30.
  * *n_out = survivors (row-major order), *n_total_out = all candidates before resolution. */
 int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double quality, int min_dist,
-                                      int cap, uint32_t* cand_xy, double* cand_score, int* n_out,
-                                      int* n_total_out, double* max_out);
+                                      int cap, uint32_t* cand_xy, double* cand_score, int32_t* cand_full_index,
+                                      int* n_out, int* n_total_out, double* max_out);
+/* cand_full_index[k] (optional) = position of survivor k in the row-major list of ALL candidates, whose
+ * scores stay in HBM until the next Shi-Tomasi / RANSAC call and can be fetched with: */
+int sfmx_shi_tomasi_fetch_all_scores(sfmx_ctx* ctx, int n_total, double* scores_out);
 
 /* ---- KLT: replaces KLTTracker::track_one fwd+bwd and the FB test (T:356-362, 402-460) ------- */
 typedef struct sfmx_klt_cfg {

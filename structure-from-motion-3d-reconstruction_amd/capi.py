@@ -21,7 +21,7 @@ SYMBOLS = [
     "sfmx_ctx_create", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_stream", "sfmx_set_timing",
     "sfmx_last_kernel_us", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
-    "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",
+    "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_scores", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",
     "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt",
 ]
@@ -207,8 +207,10 @@ class Context:
         sc = np.zeros(cap)
         n, ntot = c_int(), c_int()
         mx = c_double()
+        full = np.zeros(cap, np.int32)
         self._chk(self.lib.sfmx_shi_tomasi_candidates_pruned(self.h_, pyr.h_, c_double(quality), c_int(min_dist), c_int(cap),
-                                                             _p(xy, c_uint32), _p(sc, c_double), byref(n), byref(ntot), byref(mx)))
+                                                             _p(xy, c_uint32), _p(sc, c_double), _p(full, c_int32), byref(n),
+                                                             byref(ntot), byref(mx)))
         m = min(n.value, cap)
         return ((xy[:m] & 0x7FFF).astype(np.int32), ((xy[:m] >> 16) & 0x7FFF).astype(np.int32), (xy[:m] >> 31).astype(bool),
                 sc[:m].copy(), n.value, ntot.value)

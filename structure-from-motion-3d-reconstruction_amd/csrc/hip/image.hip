@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ sc
   if (rejected) { state[(size_t)y * w + x] = 3; *changed = 1; }
   else if (!may_be_blocked) { state[(size_t)y * w + x] = 2; *changed = 1; }  // (A)
 }
-// ordered compaction of flag in {1,2}
+// ordered compaction (row-major): survivors (state 1 or 2) with their score and their index in the list
+// of ALL candidates (state != 0), plus that full list's scores (kept resident for the tie-order replay)
 __global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* __restrict__ row_count, int* __restrict__ row_all) {
   const int y = blockIdx.x;
   int c = 0, a = 0;
@@ -312,26 +313,33 @@ __global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* _
     int t = 0, ta = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); i++) { t += part[i]; ta += parta[i]; }
     row_count[y] = t;
-    atomicAdd(row_all, ta);
+    row_all[y] = ta;
   }
 }
 __global__ void k_flag_row_write(const double* __restrict__ score, const uint8_t* __restrict__ flag, int w, const int* __restrict__ row_off,
-                                 int cap, uint32_t* __restrict__ cand_xy, double* __restrict__ cand_s) {
+                                 const int* __restrict__ row_off_all, int cap, uint32_t* __restrict__ cand_xy, double* __restrict__ cand_s,
+                                 int32_t* __restrict__ cand_full, double* __restrict__ all_s) {
   const int y = blockIdx.x;
-  int off = row_off[y];
+  int off = row_off[y], offa = row_off_all[y];
   for (int base = 0; base < w; base += 64) {
     const int x = base + (int)threadIdx.x;
     const uint8_t f = (x < w) ? flag[(size_t)y * w + x] : 0;
-    const bool hit = (f == 1 || f == 2);
-    const unsigned long long m = __ballot(hit);
+    const bool hit = (f == 1 || f == 2), any = (f != 0);
+    const unsigned long long m = __ballot(hit), ma = __ballot(any);
+    const unsigned long long below = (1ull << threadIdx.x) - 1ull;
+    const int posa = offa + __popcll(ma & below);
+    const double s = any ? score[(size_t)y * w + x] : 0.0;
+    if (any) all_s[posa] = s;
     if (hit) {
-      const int pos = off + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      const int pos = off + __popcll(m & below);
       if (pos < cap) {
         cand_xy[pos] = (uint32_t)x | ((uint32_t)y << 16) | (f == 2 ? 0x80000000u : 0u);
-        cand_s[pos] = score[(size_t)y * w + x];
+        cand_s[pos] = s;
+        cand_full[pos] = posa;
       }
     }
     off += __popcll(m);
+    offa += __popcll(ma);
   }
 }
 
@@ -407,62 +415,73 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
 }
 
 int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap, uint32_t* cand_xy,
-                                      double* cand_score, int* n_out, int* n_total_out, double* max_out) {
+                                      double* cand_score, int32_t* cand_full_index, int* n_out, int* n_total_out, double* max_out) {
   SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 32768 && p->h < 32768 && min_dist >= 1 && min_dist <= SR_MAXR + 1);
   const size_t n = (size_t)p->w * p->h;
   c->resident_points = 0;
+  c->shi_full_count = 0;
   SFMX_HIP(c, c->d[0].ensure(n * 8));
   SFMX_HIP(c, c->d[1].ensure(64));
-  SFMX_HIP(c, c->d[2].ensure((size_t)(p->h + 4) * 4 + 64));
-  SFMX_HIP(c, c->d[3].ensure((size_t)cap * 4));
+  SFMX_HIP(c, c->d[2].ensure((size_t)(2 * p->h + 8) * 4 + 64));
+  SFMX_HIP(c, c->d[3].ensure((size_t)cap * 8));   // xy (u32) + full index (i32)
   SFMX_HIP(c, c->d[4].ensure((size_t)cap * 8));
   SFMX_HIP(c, c->d[5].ensure(n + 64));
+  SFMX_HIP(c, c->d[6].ensure(n * 8));             // scores of all candidates, row-major
   unsigned long long* d_max = c->d[1].as<unsigned long long>();
-  int* d_rows = c->d[2].as<int>();
-  int* d_total = d_rows + p->h;
-  int* d_all = d_rows + p->h + 1;
+  int* d_rows = c->d[2].as<int>();                // [h] survivors per row -> offsets, [h] = total
+  int* d_rows_all = d_rows + p->h + 1;            // [h] candidates per row -> offsets, [h] = total
+  int* d_changed = d_rows_all + p->h + 1;
   uint8_t* d_flag = c->d[5].as<uint8_t>();
+  uint32_t* d_xy = c->d[3].as<uint32_t>();
+  int32_t* d_full = reinterpret_cast<int32_t*>(d_xy + cap);
   int rc = launch_score(c, p, c->d[0].as<double>(), d_max);
   if (rc) return rc;
-  SFMX_HIP(c, hipMemsetAsync(d_all, 0, 8, c->stream));
-  int* d_changed = d_all + 1;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag);
-  // Rounds until nothing changes (checked every 3 rounds; stopping early would also be safe: undecided
-  // pixels simply travel to the host).  The fixpoint is normally reached in 6-9 rounds.
+  // A fixed number of rounds, queued back to back with no host round trip in between.  The fixpoint is
+  // normally reached in 12-16 rounds; rounds after that cost one byte load per pixel, and stopping
+  // before the fixpoint is always safe (undecided pixels simply travel to the host).
   {
     const int r = min_dist - 1;
     const size_t shm = (size_t)(SR_TX + 2 * r) * (SR_TY + 2 * r) * 9 + 16;
     dim3 gt((p->w + SR_TX - 1) / SR_TX, (p->h + SR_TY - 1) / SR_TY);
-    for (int batch = 0; batch < 8; ++batch) {
-      SFMX_HIP(c, hipMemsetAsync(d_changed, 0, 4, c->stream));
-      for (int k = 0; k < 3; ++k) k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
-      SFMX_HIP(c, hipGetLastError());
-      int changed = 0;
-      SFMX_HIP(c, hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, c->stream));
-      SFMX_HIP(c, hipStreamSynchronize(c->stream));
-      if (!changed) break;
-    }
+    for (int k = 0; k < 18; ++k) k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
   }
-  k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_all);
-  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_total);
-  k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, cap, c->d[3].as<uint32_t>(), c->d[4].as<double>());
+  k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_rows_all);
+  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_rows + p->h);
+  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows_all, p->h, d_rows_all + p->h);
+  k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, d_rows_all, cap, d_xy, c->d[4].as<double>(), d_full,
+                                          c->d[6].as<double>());
   SFMX_HIP(c, hipGetLastError());
-  int tot[2] = {0, 0};
+  int tot = 0, tot_all = 0;
   double mx = 0;
-  SFMX_HIP(c, hipMemcpyAsync(tot, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&tot, d_rows + p->h, 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(&tot_all, d_rows_all + p->h, 4, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   KernelTimer(c).collect();
-  const int m = tot[0] < cap ? tot[0] : cap;
+  const int m = tot < cap ? tot : cap;
   if (m > 0) {
-    SFMX_HIP(c, hipMemcpyAsync(cand_xy, c->d[3].p, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipMemcpyAsync(cand_xy, d_xy, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
     SFMX_HIP(c, hipMemcpyAsync(cand_score, c->d[4].p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
+    if (cand_full_index) SFMX_HIP(c, hipMemcpyAsync(cand_full_index, d_full, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
     SFMX_HIP(c, hipStreamSynchronize(c->stream));
   }
-  *n_out = tot[0];
-  if (n_total_out) *n_total_out = tot[1];
+  c->shi_full_count = tot_all;
+  *n_out = tot;
+  if (n_total_out) *n_total_out = tot_all;
   if (max_out) *max_out = mx;
+  return SFMX_OK;
+}
+
+// scores of ALL candidates (row-major) of the preceding sfmx_shi_tomasi_candidates_pruned call, still in HBM
+int sfmx_shi_tomasi_fetch_all_scores(sfmx_ctx* c, int n_total, double* scores_out) {
+  SFMX_REQUIRE(c, c && scores_out && n_total > 0 && n_total == c->shi_full_count);
+  const size_t nb = (size_t)n_total * 8;
+  SFMX_HIP(c, c->h[1].ensure(nb));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, c->d[6].p, nb, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(scores_out, c->h[1].p, nb);
   return SFMX_OK;
 }
 

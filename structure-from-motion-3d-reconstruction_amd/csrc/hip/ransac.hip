@@ -410,6 +410,7 @@ int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, co
                       int32_t* count_out) {
   SFMX_REQUIRE(c, c && E9 && mask_out && n > 0 && ((xi && xj) || (!xi && !xj && c->resident_points == n)));
   const size_t pb = (size_t)n * 16;
+  c->shi_full_count = 0;
   SFMX_HIP(c, c->d[6].ensure(128));
   SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
   if (xi) {

@@ -65,6 +65,7 @@ struct sfmx_ctx {
   DevBuf d[8];
   PinBuf h[4];
   int resident_points = 0;  // #correspondences left in d[0]/d[1] by the last RANSAC call
+  int shi_full_count = 0;   // #candidate scores left in d[6] by the last pruned Shi-Tomasi call
 };
 
 struct sfmx_pyramid {

@@ -83,7 +83,9 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
     // ---- fast path: the device has already removed every candidate that is certainly rejected
     int n = 0, n_total = 0;
     double maxv = 0;
-    check(ctx_, sfmx_shi_tomasi_candidates_pruned(ctx_, pyr, quality, min_dist, cap, cand_xy_.data(), cand_s_.data(), &n, &n_total, &maxv),
+    if ((int)cand_full_.size() < cap) cand_full_.resize((size_t)cap);
+    check(ctx_, sfmx_shi_tomasi_candidates_pruned(ctx_, pyr, quality, min_dist, cap, cand_xy_.data(), cand_s_.data(), cand_full_.data(), &n,
+                                                  &n_total, &maxv),
           "shi_tomasi_candidates_pruned");
     if (clk_) { clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_); clk_->shi_gpu += since(t0); }
     std::vector<Cand> cands((size_t)n);
@@ -121,29 +123,22 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
       // ---- tie order from a selective replay of libstdc++'s introsort on the FULL candidate list
       if (clk_) clk_->shi_fallbacks++;
       const auto tr0 = Clock::now();
-      std::vector<std::uint32_t> sel_xy((size_t)n);
-      for (int k = 0; k < n; k++) sel_xy[(size_t)k] = cand_xy_[(size_t)k] & 0x7fff7fffu;  // pruned list, row-major order
+      // the scores of ALL candidates are still resident in HBM; survivors know their index in that list
+      const int nf = n_total;
+      if ((int)all_s_.size() < nf) all_s_.resize((size_t)nf);
+      check(ctx_, sfmx_shi_tomasi_fetch_all_scores(ctx_, nf, all_s_.data()), "shi_tomasi_fetch_all_scores");
       std::vector<Cand> pruned((size_t)n);
-      for (int k = 0; k < n; k++) pruned[(size_t)k] = {(int)(sel_xy[(size_t)k] & 0x7fffu), (int)(sel_xy[(size_t)k] >> 16), cand_s_[(size_t)k], k};
-      int nf = 0;
-      double mx2 = 0;
-      check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &nf, &mx2), "shi_tomasi_candidates");
-      if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
-      // interesting = members of the pruned list that share their score with another member
-      std::vector<std::uint8_t> tied((size_t)n, 0);
-      for (size_t a = 0; a + 1 < cands.size(); a++)
-        if (cands[a].s == cands[a + 1].s) { tied[(size_t)cands[a].idx] = 1; tied[(size_t)cands[a + 1].idx] = 1; }
+      for (int k = 0; k < n; k++)
+        pruned[(size_t)k] = {(int)(cand_xy_[(size_t)k] & 0x7fffu), (int)((cand_xy_[(size_t)k] >> 16) & 0x7fffu), cand_s_[(size_t)k], k};
       std::vector<SortKey> keys((size_t)nf);
-      std::vector<int> full_of((size_t)n, -1);
-      {
-        int k = 0;  // both lists are in row-major order: merge-walk to find each pruned member in the full list
-        for (int f = 0; f < nf; f++) {
-          const std::uint32_t xy = cand_xy_[(size_t)f];
-          std::uint32_t mark = 0;
-          if (k < n && sel_xy[(size_t)k] == xy) { full_of[(size_t)k] = f; mark = tied[(size_t)k]; k++; }
-          keys[(size_t)f] = SortKey{cand_s_[(size_t)f], (std::uint32_t)f, mark};
+      for (int f = 0; f < nf; f++) keys[(size_t)f] = SortKey{all_s_[(size_t)f], (std::uint32_t)f, 0u};
+      // interesting = survivors that share their score with another survivor
+      for (size_t a = 0; a + 1 < cands.size(); a++)
+        if (cands[a].s == cands[a + 1].s) {
+          keys[(size_t)cand_full_[(size_t)cands[a].idx]].mark = 1;
+          keys[(size_t)cand_full_[(size_t)cands[a + 1].idx]].mark = 1;
         }
-      }
+      const std::vector<std::int32_t>& full_of = cand_full_;
       if (introsort_replay_selective(keys)) {
         std::vector<int> pos((size_t)nf, 0);
         for (int f = 0; f < nf; f++) pos[(size_t)keys[(size_t)f].id] = f;

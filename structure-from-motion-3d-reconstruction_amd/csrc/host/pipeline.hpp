@@ -92,7 +92,8 @@ class GpuTracker {
   int next_id_ = 0;
   StageClock* clk_;
   std::vector<std::uint32_t> cand_xy_;
-  std::vector<double> cand_s_;
+  std::vector<double> cand_s_, all_s_;
+  std::vector<std::int32_t> cand_full_;
 };
 
 struct RelPose {

@@ -80,8 +80,9 @@ def render(scene, R, t, K, w: int, h: int, rng: np.random.Generator | None, back
 
 def make_sequence(n_frames: int, w: int = 640, h: int = 480, deg_per_frame: float = 0.3, n_blobs: int = 20000,
                   seed: int = 7, noise: bool = True, K: np.ndarray | None = None, dist: float = 0.65,
-                  start_deg: float = 0.0):
-    """Returns dict(images [F,h,w] u8, K, R [F,3,3], t [F,3], names, lat, lon)."""
+                  start_deg: float = 0.0, angles=None):
+    """Returns dict(images [F,h,w] u8, K, R [F,3,3], t [F,3], names, lat, lon).
+    angles (optional): explicit ring angle in degrees per frame (e.g. out-and-back paths that revisit a view)."""
     if K is None:
         K = K_TEMPLE.copy()
         K[0, :] *= w / 640.0
@@ -92,13 +93,16 @@ def make_sequence(n_frames: int, w: int = 640, h: int = 480, deg_per_frame: floa
     Rs = np.zeros((n_frames, 3, 3))
     ts = np.zeros((n_frames, 3))
     blob_scale = max(w / 640.0, 0.6)
+    if angles is None:
+        angles = [start_deg + f * deg_per_frame for f in range(n_frames)]
+    assert len(angles) == n_frames
     for f in range(n_frames):
-        R, t = ring_pose(start_deg + f * deg_per_frame, dist)
+        R, t = ring_pose(float(angles[f]), dist)
         Rs[f], ts[f] = R, t
         imgs[f] = render(scene, R, t, K, w, h, rng, scale=blob_scale)
     names = [f"templeR{f + 1:04d}.png" for f in range(n_frames)]
     lat = np.zeros(n_frames)
-    lon = np.array([start_deg + f * deg_per_frame for f in range(n_frames)])
+    lon = np.array([float(a) for a in angles])
     return dict(images=imgs, K=K, R=Rs, t=ts, names=names, lat=lat, lon=lon)
 
 

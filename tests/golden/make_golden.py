@@ -108,6 +108,12 @@ def ba_problem(W, P, seed, n_kf=None):
 def main():
     r = H.ref()
     assert r is not None, "oracle/_ref/libsfmref.so missing: run `make -C oracle ref` in the build container"
+    if "--e2e-only" not in sys.argv:
+        function_vectors(r)
+    end_to_end()
+
+
+def function_vectors(r):
     out = {}
 
     # ---- images / KLT
@@ -258,15 +264,26 @@ def main():
     np.savez_compressed(os.path.join(HERE, "hotpath.npz"), **out)
     print("wrote hotpath.npz with", len(out), "arrays")
 
-    # ---- end-to-end: the reference CLI on a small synthetic dataset
+
+
+def end_to_end():
+    """the reference CLI on small synthetic datasets (e2e_loop revisits earlier views so that loop closure,
+    the pose-graph solve and the second BA pass fire: T:1822-1866)"""
     cli = H.ref_cli()
-    for name, (frames, deg, cfgover) in {
-        "e2e_small": (8, 0.4, {"klt": {"max_tracks": 400, "min_tracks": 250, "min_distance": 5}}),
+    only = [a for a in sys.argv[1:] if a.startswith("e2e_")]
+    for name, (frames, deg, cfgover, size, nb, seed, angles) in {
+        "e2e_small": (8, 0.4, {"klt": {"max_tracks": 400, "min_tracks": 250, "min_distance": 5}}, (160, 120), 2500, 9, None),
         "e2e_keyframes": (10, 0.25, {"klt": {"max_tracks": 500, "min_tracks": 300, "min_distance": 4},
                                      "keyframe": {"min_inliers": 120, "parallax_px": 3.0, "min_gap": 2},
-                                     "ba": {"window": 4, "iters": 3, "max_points": 150}}),
+                                     "ba": {"window": 4, "iters": 3, "max_points": 150}}, (160, 120), 2500, 9, None),
+        "e2e_loop": (14, 0.3, {"klt": {"max_tracks": 900, "min_tracks": 600, "min_distance": 5},
+                               "keyframe": {"min_inliers": 100, "parallax_px": 1.0, "min_gap": 1},
+                               "ba": {"window": 4, "iters": 3, "max_points": 200}}, (320, 240), 6000, 13,
+                     [0, 0.3, 0.6, 0.9, 1.2, 1.5, 1.8, 1.5, 1.2, 0.9, 0.6, 0.3, 0.0, 0.3]),
     }.items():
-        seq = synth.make_sequence(frames, 160, 120, deg, n_blobs=2500, seed=9)
+        if only and name not in only:
+            continue
+        seq = synth.make_sequence(frames, size[0], size[1], deg, n_blobs=nb, seed=seed, angles=angles)
         cfg = {"common": {"system": {"frames": frames}, "klt": cfgover.get("klt", {}), "keyframe": cfgover.get("keyframe", {})},
                "cpp": {"ba": cfgover.get("ba", {})}}
         with tempfile.TemporaryDirectory() as td:

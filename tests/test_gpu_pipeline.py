@@ -36,7 +36,7 @@ def _same_files(a, b):
         assert ta == tb, f"{fn} differs:\n{ta[:400]}\n---\n{tb[:400]}"
 
 
-@pytest.mark.parametrize("name", ["e2e_small", "e2e_keyframes"])
+@pytest.mark.parametrize("name", ["e2e_small", "e2e_keyframes", "e2e_loop"])
 def test_pipeline_matches_reference_and_oracle(ctx, name, tmp_path):
     g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
     cfg = H.pipe_cfg_from_json(json.loads(str(g["config"])))

@@ -165,7 +165,7 @@ def check_e2e_against_reference(g, log, out):
     assert gp[:7] == ep[:7] and len(gp) == len(ep)
 
 
-@pytest.mark.parametrize("name", ["e2e_small", "e2e_keyframes"])
+@pytest.mark.parametrize("name", ["e2e_small", "e2e_keyframes", "e2e_loop"])
 def test_pipeline_end_to_end(name, tmp_path):
     g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
     cfg = H.pipe_cfg_from_json(json.loads(str(g["config"])))
@@ -176,3 +176,5 @@ def test_pipeline_end_to_end(name, tmp_path):
     # defined-behaviour part must at least be finite here
     rows = open(os.path.join(out, "keyframes_camera_centers.csv")).read().splitlines()[1:]
     assert all(np.isfinite([float(v) for v in r.split(",")[3:6]]).all() for r in rows)
+    if name == "e2e_loop":  # the scenario must exercise loop closure + pose graph (is_loop == 1 rows)
+        assert sum(l.endswith(",1") for l in str(g["posegraph_edges_csv"]).splitlines()) >= 3
