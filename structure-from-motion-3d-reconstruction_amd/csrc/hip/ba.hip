@@ -496,7 +496,9 @@ static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, 
 
 static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
                            double huber, double lambda, int damp, KernelTimer& t) {
-  SFMX_HIP(c, hipMemcpyAsync(q->poses, poses_wc, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, c->h[0].ensure((size_t)q->W * 96));
+  memcpy(c->h[0].p, poses_wc, (size_t)q->W * 96);
+  SFMX_HIP(c, hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
   const int D = 6 * q->W;
   t.start();
   k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, q->poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy,
@@ -597,10 +599,12 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
   rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
   if (rc) return rc;
   int status = 0;
-  SFMX_HIP(c, hipMemcpyAsync(dx_out, q->work, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(&status, dstatus, 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 8));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, q->work, (size_t)D * 8 + 4, hipMemcpyDeviceToHost, c->stream));  // dx | status
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   t.collect();
+  memcpy(dx_out, c->h[1].p, (size_t)D * 8);
+  memcpy(&status, c->h[1].as<char>() + (size_t)D * 8, 4);
   return status ? SFMX_ERR_SINGULAR : SFMX_OK;
 }
 

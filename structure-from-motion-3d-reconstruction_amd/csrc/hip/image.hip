@@ -448,20 +448,36 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
     for (int k = 0; k < 18; ++k) k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
   }
   k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_rows_all);
-  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_rows + p->h);
-  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows_all, p->h, d_rows_all + p->h);
+  // header in d[1]: [0] max score bits (8 B) | [8] #survivors (4 B) | [12] #candidates (4 B)
+  int* d_tot = reinterpret_cast<int*>(c->d[1].as<char>() + 8);
+  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_tot);
+  k_row_scan<<<1, 64, 0, c->stream>>>(d_rows_all, p->h, d_tot + 1);
   k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, d_rows_all, cap, d_xy, c->d[4].as<double>(), d_full,
                                           c->d[6].as<double>());
   SFMX_HIP(c, hipGetLastError());
-  int tot = 0, tot_all = 0;
-  double mx = 0;
-  SFMX_HIP(c, hipMemcpyAsync(&tot, d_rows + p->h, 4, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(&tot_all, d_rows_all + p->h, 4, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(&mx, d_max, 8, hipMemcpyDeviceToHost, c->stream));
+  // ONE host round trip: the 16-byte header plus a speculative download of the first SPEC survivors
+  // (there are ~1.5-2 k of them per VGA frame) through pinned memory; a second trip only if there are more.
+  const int SPEC = cap < 4096 ? cap : 4096;
+  const size_t o_xy = 64, o_s = o_xy + (size_t)SPEC * 4, o_full = o_s + (size_t)SPEC * 8, total_pin = o_full + (size_t)SPEC * 4;
+  SFMX_HIP(c, c->h[2].ensure(total_pin));
+  char* pin = c->h[2].as<char>();
+  SFMX_HIP(c, hipMemcpyAsync(pin, c->d[1].p, 16, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(pin + o_xy, d_xy, (size_t)SPEC * 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(pin + o_s, c->d[4].p, (size_t)SPEC * 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(pin + o_full, d_full, (size_t)SPEC * 4, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   KernelTimer(c).collect();
+  double mx;
+  int tot, tot_all;
+  memcpy(&mx, pin, 8);
+  memcpy(&tot, pin + 8, 4);
+  memcpy(&tot_all, pin + 12, 4);
   const int m = tot < cap ? tot : cap;
-  if (m > 0) {
+  if (m <= SPEC) {
+    memcpy(cand_xy, pin + o_xy, (size_t)m * 4);
+    memcpy(cand_score, pin + o_s, (size_t)m * 8);
+    if (cand_full_index) memcpy(cand_full_index, pin + o_full, (size_t)m * 4);
+  } else {
     SFMX_HIP(c, hipMemcpyAsync(cand_xy, d_xy, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
     SFMX_HIP(c, hipMemcpyAsync(cand_score, c->d[4].p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
     if (cand_full_index) SFMX_HIP(c, hipMemcpyAsync(cand_full_index, d_full, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));

@@ -237,21 +237,24 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   SFMX_REQUIRE(c, xy_in != nullptr);
   const size_t nb = (size_t)n * 16;
   c->resident_points = 0;
-  SFMX_HIP(c, c->d[0].ensure(nb));       // xy_in
-  SFMX_HIP(c, c->d[1].ensure(nb));       // fwd
-  SFMX_HIP(c, c->d[2].ensure(nb));       // back
-  SFMX_HIP(c, c->d[3].ensure((size_t)n + 64));  // keep
-  SFMX_HIP(c, c->d[4].ensure(64));       // step counter
-  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xy_in, nb, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemsetAsync(c->d[4].p, 0, 8, c->stream));
+  // one device slab: [xy_in nb][fwd nb][back nb][steps 8][keep n]; one pinned slab for the upload and one
+  // for the download, so a call costs two DMA transfers and one host synchronisation
+  const size_t o_fwd = nb, o_back = 2 * nb, o_steps = 3 * nb, o_keep = 3 * nb + 8, dev_bytes = o_keep + (size_t)n;
+  SFMX_HIP(c, c->d[0].ensure(dev_bytes + 64));
+  SFMX_HIP(c, c->h[0].ensure(nb));
+  SFMX_HIP(c, c->h[1].ensure(dev_bytes - nb));
+  char* dbase = c->d[0].as<char>();
+  memcpy(c->h[0].p, xy_in, nb);
+  SFMX_HIP(c, hipMemcpyAsync(dbase, c->h[0].p, nb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemsetAsync(dbase + o_steps, 0, 8, c->stream));
   const int r = cfg->win_radius, npix = (2 * r + 1) * (2 * r + 1), npad = (npix + 1) & ~1;
   const size_t shmem = (size_t)((2 * KLT_P * KLT_PS_FOR(r) + 3) & ~3) * sizeof(float) + (size_t)5 * npad * sizeof(double);
   KernelTimer t(c);
   t.start();
 #define KLT_LAUNCH(RR)                                                                                                          \
-  k_klt_track<RR><<<n, 64, shmem, c->stream>>>(make_desc(pa), make_desc(pb), c->d[0].as<double>(), n, cfg->levels, cfg->iters, \
-                                               cfg->fb_thresh, c->d[1].as<double>(), c->d[2].as<double>(), c->d[3].as<uint8_t>(), \
-                                               c->d[4].as<unsigned long long>())
+  k_klt_track<RR><<<n, 64, shmem, c->stream>>>(make_desc(pa), make_desc(pb), reinterpret_cast<double*>(dbase), n, cfg->levels, cfg->iters, \
+                                               cfg->fb_thresh, reinterpret_cast<double*>(dbase + o_fwd), reinterpret_cast<double*>(dbase + o_back), \
+                                               reinterpret_cast<uint8_t*>(dbase + o_keep), reinterpret_cast<unsigned long long*>(dbase + o_steps))
   switch (r) {
     case 1: KLT_LAUNCH(1); break;
     case 2: KLT_LAUNCH(2); break;
@@ -264,13 +267,15 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
 #undef KLT_LAUNCH
   t.stop();
   SFMX_HIP(c, hipGetLastError());
-  SFMX_HIP(c, hipMemcpyAsync(xy_fwd, c->d[1].p, nb, hipMemcpyDeviceToHost, c->stream));
-  if (xy_back) SFMX_HIP(c, hipMemcpyAsync(xy_back, c->d[2].p, nb, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(keep, c->d[3].p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  unsigned long long steps = 0;
-  if (n_steps_out) SFMX_HIP(c, hipMemcpyAsync(&steps, c->d[4].p, 8, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, dbase + o_fwd, dev_bytes - nb, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   t.collect();
+  const char* hp = c->h[1].as<char>();
+  memcpy(xy_fwd, hp, nb);
+  if (xy_back) memcpy(xy_back, hp + nb, nb);
+  unsigned long long steps = 0;
+  memcpy(&steps, hp + 2 * nb, 8);
+  memcpy(keep, hp + 2 * nb + 8, (size_t)n);
   if (n_steps_out) *n_steps_out = steps;
   return SFMX_OK;
 }

@@ -355,17 +355,13 @@ __global__ void k_argmax(const int32_t* __restrict__ counts, int H, int32_t* __r
   }
 }
 
-__global__ void k_sampson_mask(const double* __restrict__ xi, const double* __restrict__ xj, int n, const double* __restrict__ E,
-                               double thr, uint8_t* __restrict__ mask, int32_t* __restrict__ count) {
+struct E9 { double e[9]; };
+__global__ void k_sampson_mask(const double* __restrict__ xi, const double* __restrict__ xj, int n, E9 E, double thr, uint8_t* __restrict__ mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  int hit = 0;
-  if (i < n) {
-    const double err = sampson_eval(E[0], E[1], E[2], E[3], E[4], E[5], E[6], E[7], E[8], xi[2 * i], xi[2 * i + 1], xj[2 * i], xj[2 * i + 1]);
-    hit = (err < thr) ? 1 : 0;
-    mask[i] = (uint8_t)hit;
-  }
-  const unsigned long long m = __ballot(hit);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (int)__popcll(m));
+  if (i >= n) return;
+  const double err = sampson_eval(E.e[0], E.e[1], E.e[2], E.e[3], E.e[4], E.e[5], E.e[6], E.e[7], E.e[8], xi[2 * i], xi[2 * i + 1], xj[2 * i],
+                                  xj[2 * i + 1]);
+  mask[i] = (err < thr) ? 1 : 0;
 }
 
 extern "C" {
@@ -373,32 +369,40 @@ extern "C" {
 int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, const int32_t* idx8, int H, double thr,
                       int32_t* counts_out, int32_t* best_iter, int32_t* best_count, double* E_out) {
   SFMX_REQUIRE(c, c && xi && xj && idx8 && n >= 8 && H > 0 && best_iter && best_count);
-  const size_t pb = (size_t)n * 16;
+  const size_t pb = (size_t)n * 16, ib = (size_t)H * 32;
   SFMX_HIP(c, c->d[0].ensure(pb));
   SFMX_HIP(c, c->d[1].ensure(pb));
-  SFMX_HIP(c, c->d[2].ensure((size_t)H * 32));
+  SFMX_HIP(c, c->d[2].ensure(ib));
   SFMX_HIP(c, c->d[3].ensure((size_t)H * 72));
-  SFMX_HIP(c, c->d[4].ensure((size_t)H * 4 + 64));
+  SFMX_HIP(c, c->d[4].ensure((size_t)H * 4 + 64));   // [counts H*4][best_iter, best_count]
   SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
-  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xi, pb, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(c->d[2].p, idx8, (size_t)H * 32, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, c->h[0].ensure(2 * pb + ib));
+  SFMX_HIP(c, c->h[1].ensure((size_t)H * 4 + 64));
+  char* hin = c->h[0].as<char>();
+  memcpy(hin, xi, pb);
+  memcpy(hin + pb, xj, pb);
+  memcpy(hin + 2 * pb, idx8, ib);
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, hin, pb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, hin + pb, pb, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[2].p, hin + 2 * pb, ib, hipMemcpyHostToDevice, c->stream));
   c->resident_points = n;
+  int32_t* d_best = c->d[4].as<int32_t>() + H;
   KernelTimer t(c);
   t.start();
   k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[2].as<int32_t>(), H, 120,
                                                         c->d[3].as<double>());
   k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[3].as<double>(), H,
                                                               thr, c->d[4].as<int32_t>());
-  k_argmax<<<1, 256, 0, c->stream>>>(c->d[4].as<int32_t>(), H, c->d[5].as<int32_t>());
+  k_argmax<<<1, 256, 0, c->stream>>>(c->d[4].as<int32_t>(), H, d_best);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   int32_t best2[2] = {0, 0};
-  SFMX_HIP(c, hipMemcpyAsync(best2, c->d[5].p, 8, hipMemcpyDeviceToHost, c->stream));
-  if (counts_out) SFMX_HIP(c, hipMemcpyAsync(counts_out, c->d[4].p, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, c->d[4].p, (size_t)H * 4 + 8, hipMemcpyDeviceToHost, c->stream));
   if (E_out) SFMX_HIP(c, hipMemcpyAsync(E_out, c->d[3].p, (size_t)H * 72, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   t.collect();
+  if (counts_out) memcpy(counts_out, c->h[1].p, (size_t)H * 4);
+  memcpy(best2, c->h[1].as<char>() + (size_t)H * 4, 8);
   *best_iter = best2[0];
   *best_count = best2[1];
   return SFMX_OK;
@@ -406,13 +410,12 @@ int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, co
 
 // xi == xj == NULL reuses the correspondences left in HBM by the preceding sfmx_ransac_score call
 // (n must match); otherwise they are uploaded (n*32 bytes).
-int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, const double* E9, double thr, uint8_t* mask_out,
+int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, const double* E9in, double thr, uint8_t* mask_out,
                       int32_t* count_out) {
-  SFMX_REQUIRE(c, c && E9 && mask_out && n > 0 && ((xi && xj) || (!xi && !xj && c->resident_points == n)));
+  SFMX_REQUIRE(c, c && E9in && mask_out && n > 0 && ((xi && xj) || (!xi && !xj && c->resident_points == n)));
   const size_t pb = (size_t)n * 16;
-  c->shi_full_count = 0;
-  SFMX_HIP(c, c->d[6].ensure(128));
   SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
+  SFMX_HIP(c, c->h[2].ensure((size_t)n + 64));
   if (xi) {
     SFMX_HIP(c, c->d[0].ensure(pb));
     SFMX_HIP(c, c->d[1].ensure(pb));
@@ -420,17 +423,16 @@ int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, co
     SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
     c->resident_points = n;
   }
-  SFMX_HIP(c, hipMemcpyAsync(c->d[6].p, E9, 72, hipMemcpyHostToDevice, c->stream));
-  int32_t* d_cnt = reinterpret_cast<int32_t*>(c->d[6].as<char>() + 96);
-  SFMX_HIP(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
-  uint8_t* d_mask = c->d[5].as<uint8_t>() + 64;  // d[5][0..7] holds the argmax pair of ransac_score
-  k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[6].as<double>(), thr,
-                                                       d_mask, d_cnt);
+  E9 E;
+  memcpy(E.e, E9in, 72);
+  uint8_t* d_mask = c->d[5].as<uint8_t>() + 64;
+  k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, E, thr, d_mask);
   SFMX_HIP(c, hipGetLastError());
-  int32_t cnt = 0;
-  SFMX_HIP(c, hipMemcpyAsync(mask_out, d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[2].p, d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(mask_out, c->h[2].p, (size_t)n);
+  int32_t cnt = 0;
+  for (int i = 0; i < n; i++) cnt += mask_out[i];  // n <= a few thousand bytes
   if (count_out) *count_out = cnt;
   return SFMX_OK;
 }

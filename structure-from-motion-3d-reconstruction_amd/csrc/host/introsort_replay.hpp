@@ -63,17 +63,25 @@ inline int count_marked(const SortKey* first, const SortKey* last) {
   for (const SortKey* p = first; p != last; ++p) c += (int)p->mark;
   return c;
 }
-// returns false if the depth limit is hit (the real sort would switch to heapsort: not replayed)
-inline bool loop(SortKey* first, SortKey* last, long depth_limit, bool selective) {
+// returns false if the depth limit is hit (the real sort would switch to heapsort: not replayed).
+// `marked` = number of interesting elements in [first,last) (only used in selective mode): after each
+// partition only the smaller side is counted, the other follows by subtraction.
+inline bool loop(SortKey* first, SortKey* last, long depth_limit, bool selective, int marked) {
   while (last - first > 16) {
     if (depth_limit == 0) return false;
     --depth_limit;
     SortKey* cut = partition_pivot(first, last);
-    if (!selective || count_marked(cut, last) >= 2) {
-      if (!loop(cut, last, depth_limit, selective)) return false;
+    int right = 0, left = 0;
+    if (selective) {
+      if (last - cut < cut - first) { right = count_marked(cut, last); left = marked - right; }
+      else { left = count_marked(first, cut); right = marked - left; }
+    }
+    if (!selective || right >= 2) {
+      if (!loop(cut, last, depth_limit, selective, right)) return false;
     }
     last = cut;
-    if (selective && count_marked(first, last) < 2) return true;
+    marked = left;
+    if (selective && marked < 2) return true;
   }
   return true;
 }
@@ -86,7 +94,9 @@ inline long lg(long n) { long k = 0; while (n > 1) { n >>= 1; ++k; } return k; }
 // the real std::sort output.  Returns false when the replay has to give up (depth limit).
 inline bool introsort_replay_selective(std::vector<SortKey>& keys) {
   if (keys.size() < 2) return true;
-  return introsort_detail::loop(keys.data(), keys.data() + keys.size(), 2 * introsort_detail::lg((long)keys.size()), true);
+  const int marked = introsort_detail::count_marked(keys.data(), keys.data() + keys.size());
+  if (marked < 2) return true;
+  return introsort_detail::loop(keys.data(), keys.data() + keys.size(), 2 * introsort_detail::lg((long)keys.size()), true, marked);
 }
 
 // Full replay: must reproduce std::sort exactly (used by the tests to pin the replica).
@@ -95,7 +105,7 @@ inline bool introsort_replay_full(std::vector<SortKey>& keys) {
   if (keys.size() < 2) return true;
   SortKey* first = keys.data();
   SortKey* last = first + keys.size();
-  if (!loop(first, last, 2 * lg((long)keys.size()), false)) return false;
+  if (!loop(first, last, 2 * lg((long)keys.size()), false, 0)) return false;
   // __final_insertion_sort: guarded insertion on the first 16, unguarded on the rest
   auto linear_insert = [](SortKey* lastp) {
     SortKey val = *lastp;

@@ -575,7 +575,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   MapState& map = out.map;
   std::vector<PGEdge>& edges = out.edges;
   std::vector<std::vector<float>> kf_desc;
-  std::unordered_map<int, std::vector<std::pair<int, V2>>> track_hist;
+  Arena* arena = out.arena.get();
+  ArenaMap<int, std::vector<std::pair<int, V2>>> track_hist(0, std::hash<int>(), std::equal_to<int>(),
+                                                              ArenaAlloc<std::pair<const int, std::vector<std::pair<int, V2>>>>(arena));
   int last_kf_frame = -999999;
   const int frames = cfg.frames;
   std::ostringstream so;
@@ -589,7 +591,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   for (int fi = 0; fi < std::min(frames, src.count()); ++fi) {
     StepOut step = tracker.step(src, fi);
     if (step.prev_pts.empty()) {  // first keyframe (T:1715-1733)
-      Keyframe kf;
+      Keyframe kf(arena);
       kf.kf_id = (int)kfs.size();
       kf.frame_idx = fi;
       kf.img_name = meta[(size_t)fi].name;
@@ -627,7 +629,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       else make_kf = parallax >= cfg.kf_parallax_px;
     }
     if (make_kf) {
-      Keyframe kf;
+      Keyframe kf(arena);
       kf.kf_id = (int)kfs.size();
       kf.frame_idx = fi;
       kf.img_name = meta[(size_t)fi].name;

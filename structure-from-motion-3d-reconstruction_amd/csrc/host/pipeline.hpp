@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../../include/sfmx.h"
+#include "arena.hpp"
 #include "host_math.hpp"
 
 namespace sfmx_host {
@@ -111,7 +112,9 @@ struct Keyframe {
   int kf_id = 0, frame_idx = 0;
   std::string img_name;
   Pose pose;
-  std::unordered_map<int, V2> obs;
+  ArenaMap<int, V2> obs;
+  Keyframe() = default;
+  explicit Keyframe(Arena* a) : obs(0, std::hash<int>(), std::equal_to<int>(), ArenaAlloc<std::pair<const int, V2>>(a)) {}
 };
 struct MapPoint {
   int pid = 0, tid = 0;
@@ -120,8 +123,12 @@ struct MapPoint {
 };
 struct MapState {
   int next_pid = 0;
-  std::unordered_map<int, int> tid2pid;
-  std::unordered_map<int, MapPoint> pts;
+  ArenaMap<int, int> tid2pid;
+  ArenaMap<int, MapPoint> pts;
+  MapState() = default;
+  explicit MapState(Arena* a)
+      : tid2pid(0, std::hash<int>(), std::equal_to<int>(), ArenaAlloc<std::pair<const int, int>>(a)),
+        pts(0, std::hash<int>(), std::equal_to<int>(), ArenaAlloc<std::pair<const int, MapPoint>>(a)) {}
   bool has(int tid) const { return tid2pid.find(tid) != tid2pid.end(); }
   int add(int tid, V3 Xw);
   void add_obs(int tid, int kf_id, V2 uv);
@@ -163,9 +170,10 @@ struct FrameMeta {
   bool has_ang = false;
 };
 struct PipelineResult {
+  std::unique_ptr<Arena> arena = std::make_unique<Arena>();  // declared first: outlives the maps below
   std::vector<Keyframe> kfs;
   std::vector<PGEdge> edges;
-  MapState map;
+  MapState map{arena.get()};
   std::string log;  // exactly what the reference prints to stdout
   StageClock clock;
 };
