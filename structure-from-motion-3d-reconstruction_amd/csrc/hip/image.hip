@@ -6,6 +6,10 @@
 //   score map:           read w*h (u8), write 8*w*h (f64)
 #include "sfmx_internal.h"
 
+#include <cstdlib>
+#include <utility>
+#include <vector>
+
 // ------------------------------------------------------------------------------------------ pyramid
 // One thread per output pixel; 2x2 box, integer sum / 4 (truncation), +1 neighbours clamped.
 __global__ void k_downsample2(const uint8_t* __restrict__ src, int sw, int sh, uint8_t* __restrict__ dst, int dw, int dh) {
@@ -414,22 +418,30 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
   return SFMX_OK;
 }
 
-int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap, uint32_t* cand_xy,
-                                      double* cand_score, int32_t* cand_full_index, int* n_out, int* n_total_out, double* max_out) {
-  SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 32768 && p->h < 32768 && min_dist >= 1 && min_dist <= SR_MAXR + 1);
-  const size_t n = (size_t)p->w * p->h;
-  c->resident_points = 0;
-  c->shi_full_count = 0;
-  SFMX_HIP(c, c->d[0].ensure(n * 8));
-  SFMX_HIP(c, c->d[1].ensure(64));
-  SFMX_HIP(c, c->d[2].ensure((size_t)(2 * p->h + 8) * 4 + 64));
-  SFMX_HIP(c, c->d[3].ensure((size_t)cap * 8));   // xy (u32) + full index (i32)
-  SFMX_HIP(c, c->d[4].ensure((size_t)cap * 8));
-  SFMX_HIP(c, c->d[5].ensure(n + 64));
-  SFMX_HIP(c, c->d[6].ensure(n * 8));             // scores of all candidates, row-major
+// The whole device side of the call -- score map, 18 fixpoint rounds, ordered compaction and the
+// speculative download into pinned memory -- is ~30 launches of 2-30 us kernels: launch-bound when issued
+// one by one (~10 us of host time each).  It is captured ONCE per (buffers, image, parameters) signature
+// into a hipGraph and replayed afterwards: one graph launch + one synchronisation per call.
+struct ShiGraphKey {
+  const void* img; void* d0; void* d1; void* d2; void* d3; void* d4; void* d5; void* d6; void* pin;
+  int w, h, md, cap;
+  double quality;
+  bool operator==(const ShiGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct ShiGraph { ShiGraphKey key; hipGraphExec_t exec; };
+static std::vector<ShiGraph>& shi_graphs(sfmx_ctx* c) {
+  static std::vector<std::pair<sfmx_ctx*, std::vector<ShiGraph>>> all;
+  for (auto& e : all) if (e.first == c) return e.second;
+  all.emplace_back(c, std::vector<ShiGraph>());
+  return all.back().second;
+}
+#define SHI_SPEC 4096
+#define SHI_ROUNDS 18
+
+static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap) {
   unsigned long long* d_max = c->d[1].as<unsigned long long>();
-  int* d_rows = c->d[2].as<int>();                // [h] survivors per row -> offsets, [h] = total
-  int* d_rows_all = d_rows + p->h + 1;            // [h] candidates per row -> offsets, [h] = total
+  int* d_rows = c->d[2].as<int>();                // [h] survivors per row -> offsets
+  int* d_rows_all = d_rows + p->h + 1;            // [h] candidates per row -> offsets
   int* d_changed = d_rows_all + p->h + 1;
   uint8_t* d_flag = c->d[5].as<uint8_t>();
   uint32_t* d_xy = c->d[3].as<uint32_t>();
@@ -438,14 +450,14 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   if (rc) return rc;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag);
-  // A fixed number of rounds, queued back to back with no host round trip in between.  The fixpoint is
-  // normally reached in 12-16 rounds; rounds after that cost one byte load per pixel, and stopping
-  // before the fixpoint is always safe (undecided pixels simply travel to the host).
+  // A fixed number of rounds, queued back to back.  The fixpoint is normally reached in 12-16 rounds;
+  // rounds after that cost one byte load per pixel, and stopping before the fixpoint is always safe
+  // (undecided pixels simply travel to the host).
   {
     const int r = min_dist - 1;
     const size_t shm = (size_t)(SR_TX + 2 * r) * (SR_TY + 2 * r) * 9 + 16;
     dim3 gt((p->w + SR_TX - 1) / SR_TX, (p->h + SR_TY - 1) / SR_TY);
-    for (int k = 0; k < 18; ++k) k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
+    for (int k = 0; k < SHI_ROUNDS; ++k) k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
   }
   k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_rows_all);
   // header in d[1]: [0] max score bits (8 B) | [8] #survivors (4 B) | [12] #candidates (4 B)
@@ -455,18 +467,77 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, d_rows_all, cap, d_xy, c->d[4].as<double>(), d_full,
                                           c->d[6].as<double>());
   SFMX_HIP(c, hipGetLastError());
-  // ONE host round trip: the 16-byte header plus a speculative download of the first SPEC survivors
-  // (there are ~1.5-2 k of them per VGA frame) through pinned memory; a second trip only if there are more.
-  const int SPEC = cap < 4096 ? cap : 4096;
-  const size_t o_xy = 64, o_s = o_xy + (size_t)SPEC * 4, o_full = o_s + (size_t)SPEC * 8, total_pin = o_full + (size_t)SPEC * 4;
-  SFMX_HIP(c, c->h[2].ensure(total_pin));
+  // the 16-byte header plus a speculative download of the first SPEC survivors (there are ~1.5-2 k per
+  // VGA frame) through pinned memory; a second trip happens only if there are more
+  const int SPEC = cap < SHI_SPEC ? cap : SHI_SPEC;
+  const size_t o_xy = 64, o_s = o_xy + (size_t)SPEC * 4, o_full = o_s + (size_t)SPEC * 8;
   char* pin = c->h[2].as<char>();
   SFMX_HIP(c, hipMemcpyAsync(pin, c->d[1].p, 16, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(pin + o_xy, d_xy, (size_t)SPEC * 4, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(pin + o_s, c->d[4].p, (size_t)SPEC * 8, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(pin + o_full, d_full, (size_t)SPEC * 4, hipMemcpyDeviceToHost, c->stream));
+  return SFMX_OK;
+}
+
+int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap, uint32_t* cand_xy,
+                                      double* cand_score, int32_t* cand_full_index, int* n_out, int* n_total_out, double* max_out) {
+  SFMX_REQUIRE(c, c && p && cand_xy && cand_score && n_out && cap > 0 && p->w < 32768 && p->h < 32768 && min_dist >= 1 && min_dist <= SR_MAXR + 1);
+  const size_t n = (size_t)p->w * p->h;
+  c->resident_points = 0;
+  c->shi_full_count = 0;
+  const int SPEC = cap < SHI_SPEC ? cap : SHI_SPEC;
+  SFMX_HIP(c, c->d[0].ensure(n * 8));
+  SFMX_HIP(c, c->d[1].ensure(64));
+  SFMX_HIP(c, c->d[2].ensure((size_t)(2 * p->h + 8) * 4 + 64));
+  SFMX_HIP(c, c->d[3].ensure((size_t)cap * 8));   // xy (u32) + full index (i32)
+  SFMX_HIP(c, c->d[4].ensure((size_t)cap * 8));
+  SFMX_HIP(c, c->d[5].ensure(n + 64));
+  SFMX_HIP(c, c->d[6].ensure(n * 8));             // scores of all candidates, row-major
+  SFMX_HIP(c, c->h[2].ensure(64 + (size_t)SPEC * 16));
+  uint32_t* d_xy = c->d[3].as<uint32_t>();
+  int32_t* d_full = reinterpret_cast<int32_t*>(d_xy + cap);
+
+  static const bool no_graph = getenv("SFMX_NO_GRAPH") != nullptr;
+  ShiGraphKey key;
+  memset(&key, 0, sizeof key);
+  key.img = p->base; key.d0 = c->d[0].p; key.d1 = c->d[1].p; key.d2 = c->d[2].p; key.d3 = c->d[3].p; key.d4 = c->d[4].p;
+  key.d5 = c->d[5].p; key.d6 = c->d[6].p; key.pin = c->h[2].p; key.w = p->w; key.h = p->h; key.md = min_dist; key.cap = cap;
+  key.quality = quality;
+  bool launched = false;
+  if (!no_graph && !c->timing) {
+    auto& cache = shi_graphs(c);
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : cache) if (g.key == key) exec = g.exec;
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        const int rc = shi_enqueue(c, p, quality, min_dist, cap);
+        const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+        if (rc == SFMX_OK && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+          if (cache.size() >= 8) {  // bounded cache: drop the oldest executable
+            (void)hipGraphExecDestroy(cache.front().exec);
+            cache.erase(cache.begin());
+          }
+          cache.push_back(ShiGraph{key, exec});
+        } else {
+          exec = nullptr;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+    }
+    if (exec) {
+      SFMX_HIP(c, hipGraphLaunch(exec, c->stream));
+      launched = true;
+    }
+  }
+  if (!launched) {
+    const int rc = shi_enqueue(c, p, quality, min_dist, cap);
+    if (rc) return rc;
+  }
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   KernelTimer(c).collect();
+  const size_t o_xy = 64, o_s = o_xy + (size_t)SPEC * 4, o_full = o_s + (size_t)SPEC * 8;
+  const char* pin = c->h[2].as<char>();
   double mx;
   int tot, tot_all;
   memcpy(&mx, pin, 8);

@@ -130,7 +130,8 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
       std::vector<Cand> pruned((size_t)n);
       for (int k = 0; k < n; k++)
         pruned[(size_t)k] = {(int)(cand_xy_[(size_t)k] & 0x7fffu), (int)((cand_xy_[(size_t)k] >> 16) & 0x7fffu), cand_s_[(size_t)k], k};
-      std::vector<SortKey> keys((size_t)nf);
+      std::vector<SortKey>& keys = keys_;  // persistent: a fresh 2 MB vector per call costs more than the replay
+      keys.resize((size_t)nf);
       for (int f = 0; f < nf; f++) keys[(size_t)f] = SortKey{all_s_[(size_t)f], (std::uint32_t)f, 0u};
       // interesting = survivors that share their score with another survivor
       for (size_t a = 0; a + 1 < cands.size(); a++)
@@ -140,7 +141,8 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
         }
       const std::vector<std::int32_t>& full_of = cand_full_;
       if (introsort_replay_selective(keys)) {
-        std::vector<int> pos((size_t)nf, 0);
+        std::vector<int>& pos = pos_;
+        pos.resize((size_t)nf);
         for (int f = 0; f < nf; f++) pos[(size_t)keys[(size_t)f].id] = f;
         cands = pruned;
         std::sort(cands.begin(), cands.end(), [&](const Cand& a, const Cand& b) {

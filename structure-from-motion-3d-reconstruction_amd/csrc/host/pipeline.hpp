@@ -14,6 +14,7 @@
 #include "../../../include/sfmx.h"
 #include "arena.hpp"
 #include "host_math.hpp"
+#include "introsort_replay.hpp"
 
 namespace sfmx_host {
 
@@ -95,6 +96,8 @@ class GpuTracker {
   std::vector<std::uint32_t> cand_xy_;
   std::vector<double> cand_s_, all_s_;
   std::vector<std::int32_t> cand_full_;
+  std::vector<SortKey> keys_;
+  std::vector<int> pos_;
 };
 
 struct RelPose {
