@@ -36,6 +36,7 @@ void sfmx_ctx_destroy(sfmx_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& b : c->d) b.release();
+  for (auto& b : c->wl) b.release();
   for (auto& b : c->h) b.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);

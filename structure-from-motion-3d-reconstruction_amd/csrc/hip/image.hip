@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void k_shi_init(const double* __restrict__ sco
 #define SR_TX 64
 #define SR_TY 4
 #define SR_MAXR 15
+#define SR_INNER 1
 __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ state,
                                                    int* __restrict__ changed) {
   extern __shared__ __align__(16) unsigned char sr_mem[];
@@ -279,26 +280,172 @@ __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ sc
     tq[i] = in ? state[(size_t)gy * w + gx] : 0;
   }
   __syncthreads();
-  if (mine != 1) return;
+  // Up to SR_INNER sweeps on the staged tile: a decision taken in one sweep is visible (through the LDS
+  // state tile) to the block's other pixels in the next, so dependency chains that stay inside the tile
+  // are resolved within a single launch.  Halo states stay at their snapshot, which is always safe.
   const int cy = ty + r, cx = tx + r;
   const double s = ts[cy * lw + cx];
-  bool may_be_blocked = false, rejected = false;
-  for (int dy = -r; dy <= r && !rejected; ++dy) {
-    const int rem = md2 - dy * dy;  // dx*dx < rem
-    const double* rs = ts + (cy + dy) * lw + cx;
-    const uint8_t* rq = tq + (cy + dy) * lw + cx;
+  uint8_t st_mine = mine;
+  bool wrote = false;
+  for (int sweep = 0; sweep < SR_INNER; ++sweep) {
+    bool decided = false;
+    uint8_t ns = st_mine;
+    if (st_mine == 1) {
+      bool may_be_blocked = false, rejected = false;
+      for (int dy = -r; dy <= r && !rejected; ++dy) {
+        const int rem = md2 - dy * dy;  // dx*dx < rem
+        const double* rs = ts + (cy + dy) * lw + cx;
+        const uint8_t* rq = tq + (cy + dy) * lw + cx;
 #pragma unroll 5
-    for (int dx = -r; dx <= r; ++dx) {
-      const uint8_t st = rq[dx];
-      const double sq = rs[dx];
-      const bool rel = (dx * dx < rem) && !(dx == 0 && dy == 0) && (st == 1 || st == 2);
-      rejected |= rel && (st == 2) && (sq > s);  // (R)
-      may_be_blocked |= rel && (sq >= s);
+        for (int dx = -r; dx <= r; ++dx) {
+          const uint8_t st = rq[dx];
+          const double sq = rs[dx];
+          const bool rel = (dx * dx < rem) && !(dx == 0 && dy == 0) && (st == 1 || st == 2);
+          rejected |= rel && (st == 2) && (sq > s);  // (R)
+          may_be_blocked |= rel && (sq >= s);
+        }
+      }
+      if (rejected) { ns = 3; decided = true; }
+      else if (!may_be_blocked) { ns = 2; decided = true; }  // (A)
+    }
+    const int any = __syncthreads_or(decided);  // all scans of this sweep have read the tile
+    if (decided) {
+      st_mine = ns;
+      tq[cy * lw + cx] = ns;
+      wrote = true;
+    }
+    if (!any) break;
+    __syncthreads();
+  }
+  if (wrote) {
+    state[(size_t)y * w + x] = st_mine;
+    *changed = 1;
+  }
+}
+
+// ---- work-list sweeps -------------------------------------------------------------------------------
+// After the first (tiled, all-pixel) sweep about a third of the candidates are still undecided and the
+// dependency chains need ~30 more sweeps.  Those run on a compact list of undecided pixel indices:
+// 16 lanes cooperate on one pixel (taps of its min_dist disc come from a small offset table, ~13 per
+// lane, all loads in flight together), decide by a 16-lane ballot, and re-append the pixel to the next
+// list if it is still undecided.  Cost per sweep is proportional to the number of undecided pixels.
+// One pixel's (R)/(A) evidence gathered by 16 cooperating lanes: 8 taps per lane are in flight at a time
+// (state and score are loaded unconditionally from a safe address, so nothing serialises on a branch).
+__device__ __forceinline__ void shi_scan_taps(const double* __restrict__ score, const uint8_t* __restrict__ state, int w, int h,
+                                              const int8_t* __restrict__ taps, int ntaps, int lane16, int x, int y, uint32_t idx, double s,
+                                              bool& rejected, bool& blocked) {
+  for (int t0 = lane16; t0 < ntaps; t0 += 16 * 8) {
+    uint32_t off[8];
+    bool in[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int t = t0 + 16 * k;
+      const bool valid = t < ntaps;
+      const int xx = x + (valid ? (int)taps[2 * t] : 0), yy = y + (valid ? (int)taps[2 * t + 1] : 0);
+      in[k] = valid && xx >= 0 && xx < w && yy >= 0 && yy < h;
+      off[k] = in[k] ? (uint32_t)yy * (uint32_t)w + (uint32_t)xx : idx;
+    }
+    uint8_t st[8];
+    double sq[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[k] = state[off[k]];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sq[k] = score[off[k]];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const bool rel = in[k] && (st[k] == 1 || st[k] == 2);
+      rejected |= rel && (st[k] == 2) && (sq[k] > s);  // (R)
+      blocked |= rel && (sq[k] >= s);
     }
   }
-  if (rejected) { state[(size_t)y * w + x] = 3; *changed = 1; }
-  else if (!may_be_blocked) { state[(size_t)y * w + x] = 2; *changed = 1; }  // (A)
 }
+
+__global__ __launch_bounds__(256) void k_shi_list_build(const uint8_t* __restrict__ state, int n, uint32_t* __restrict__ list, int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool und = (i < n) && state[i] == 1;
+  const unsigned long long m = __ballot(und);
+  int base = 0;
+  if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(count, (int)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (und) list[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_shi_list_sweep(const double* __restrict__ score, int w, int h, uint8_t* __restrict__ state,
+                                                        const int8_t* __restrict__ taps, int ntaps, const uint32_t* __restrict__ list_in,
+                                                        const int* __restrict__ count_in, uint32_t* __restrict__ list_out,
+                                                        int* __restrict__ count_out) {
+  const int n = *count_in;
+  const int lane16 = threadIdx.x & 15, group = threadIdx.x >> 4;        // 16 groups of 16 lanes per block
+  const int gsh = ((threadIdx.x >> 4) & 3) * 16;                         // position of the group inside its wave
+  for (int e0 = blockIdx.x * 16; e0 < n; e0 += gridDim.x * 16) {
+    const int e = e0 + group;
+    const bool live = e < n;
+    const uint32_t idx = live ? list_in[e] : 0u;
+    const int y = (int)(idx / (uint32_t)w), x = (int)(idx - (uint32_t)y * (uint32_t)w);
+    const double s = live ? score[idx] : 0.0;
+    bool rejected = false, blocked = false;
+    if (live) shi_scan_taps(score, state, w, h, taps, ntaps, lane16, x, y, idx, s, rejected, blocked);
+    const unsigned rj = (unsigned)((__ballot(rejected) >> gsh) & 0xffffull);
+    const unsigned bl = (unsigned)((__ballot(blocked) >> gsh) & 0xffffull);
+    const bool still = live && !rj && bl;
+    if (live && lane16 == 0) {
+      if (rj) state[idx] = 3;
+      else if (!bl) state[idx] = 2;                      // (A)
+    }
+    // re-append the undecided ones (one atomic per wave)
+    const unsigned long long m = __ballot(still && lane16 == 0);
+    int base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(count_out, (int)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (still && lane16 == 0) list_out[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = idx;
+  }
+}
+
+// Tail: once the list is short, ONE 1024-thread workgroup runs the remaining sweeps back to back (global
+// writes of a sweep are visible to the whole workgroup after the barrier), instead of one ~6 us launch
+// per sweep.  Works for any list length (the block strides over it); meant for a few hundred entries.
+__global__ __launch_bounds__(1024) void k_shi_list_tail(const double* __restrict__ score, int w, int h, uint8_t* __restrict__ state,
+                                                        const int8_t* __restrict__ taps, int ntaps, uint32_t* __restrict__ list_a,
+                                                        uint32_t* __restrict__ list_b, const int* __restrict__ count_in, int max_sweeps) {
+  __shared__ int s_count[2];
+  const int lane16 = threadIdx.x & 15, group = threadIdx.x >> 4;  // 64 groups
+  const int gsh = ((threadIdx.x >> 4) & 3) * 16;
+  if (threadIdx.x == 0) { s_count[0] = *count_in; s_count[1] = 0; }
+  __syncthreads();
+  uint32_t* lin = list_a;
+  uint32_t* lout = list_b;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    const int cur = sweep & 1;
+    const int n = s_count[cur];
+    if (n == 0) break;
+    for (int e0 = 0; e0 < n; e0 += 64) {
+      const int e = e0 + group;
+      const bool live = e < n;
+      const uint32_t idx = live ? lin[e] : 0u;
+      const int y = (int)(idx / (uint32_t)w), x = (int)(idx - (uint32_t)y * (uint32_t)w);
+      const double s = live ? score[idx] : 0.0;
+      bool rejected = false, blocked = false;
+      if (live) shi_scan_taps(score, state, w, h, taps, ntaps, lane16, x, y, idx, s, rejected, blocked);
+      const unsigned rj = (unsigned)((__ballot(rejected) >> gsh) & 0xffffull);
+      const unsigned bl = (unsigned)((__ballot(blocked) >> gsh) & 0xffffull);
+      const bool still = live && !rj && bl;
+      if (live && lane16 == 0) {
+        if (rj) state[idx] = 3;
+        else if (!bl) state[idx] = 2;
+      }
+      const unsigned long long m = __ballot(still && lane16 == 0);
+      int base = 0;
+      if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(&s_count[cur ^ 1], (int)__popcll(m));
+      base = __shfl(base, 0, 64);
+      if (still && lane16 == 0) lout[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_count[cur] = 0;  // becomes the output counter of the next sweep
+    uint32_t* tmp = lin; lin = lout; lout = tmp;
+    __syncthreads();
+  }
+}
+
 // ordered compaction (row-major): survivors (state 1 or 2) with their score and their index in the list
 // of ALL candidates (state != 0), plus that full list's scores (kept resident for the tie-order replay)
 __global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* __restrict__ row_count, int* __restrict__ row_all) {
@@ -423,7 +570,7 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
 // one by one (~10 us of host time each).  It is captured ONCE per (buffers, image, parameters) signature
 // into a hipGraph and replayed afterwards: one graph launch + one synchronisation per call.
 struct ShiGraphKey {
-  const void* img; void* d0; void* d1; void* d2; void* d3; void* d4; void* d5; void* d6; void* pin;
+  const void* img; void* d0; void* d1; void* d2; void* d3; void* d4; void* d5; void* d6; void* pin; void* w0; void* w1; void* w2; void* w3;
   int w, h, md, cap;
   double quality;
   bool operator==(const ShiGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
@@ -436,7 +583,9 @@ static std::vector<ShiGraph>& shi_graphs(sfmx_ctx* c) {
   return all.back().second;
 }
 #define SHI_SPEC 4096
-#define SHI_ROUNDS 18
+#define SHI_TILED_SWEEPS 5
+#define SHI_LIST_SWEEPS 8
+#define SHI_TAIL_SWEEPS 40
 
 static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap) {
   unsigned long long* d_max = c->d[1].as<unsigned long long>();
@@ -450,14 +599,28 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   if (rc) return rc;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag);
-  // A fixed number of rounds, queued back to back.  The fixpoint is normally reached in 12-16 rounds;
-  // rounds after that cost one byte load per pixel, and stopping before the fixpoint is always safe
-  // (undecided pixels simply travel to the host).
+  // Sweep 1 over all pixels (LDS tiles), then a fixed number of work-list sweeps.  The fixpoint is normally
+  // reached after ~30 sweeps; later sweeps see an empty list and cost ~2 us, and stopping before the
+  // fixpoint is always safe (undecided pixels simply travel to the host).
   {
     const int r = min_dist - 1;
     const size_t shm = (size_t)(SR_TX + 2 * r) * (SR_TY + 2 * r) * 9 + 16;
     dim3 gt((p->w + SR_TX - 1) / SR_TX, (p->h + SR_TY - 1) / SR_TY);
-    for (int k = 0; k < SHI_ROUNDS; ++k) k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
+    for (int k = 0; k < SHI_TILED_SWEEPS; ++k)  // dense phase: LDS-tiled sweeps over all pixels
+      k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
+    const int npx = p->w * p->h;
+    uint32_t* list0 = c->wl[0].as<uint32_t>();
+    uint32_t* list1 = c->wl[1].as<uint32_t>();
+    int* counts = c->wl[2].as<int>();
+    SFMX_HIP(c, hipMemsetAsync(counts, 0, (SHI_LIST_SWEEPS + 2) * sizeof(int), c->stream));
+    k_shi_list_build<<<(npx + 255) / 256, 256, 0, c->stream>>>(d_flag, npx, list0, counts);
+    for (int k = 0; k < SHI_LIST_SWEEPS; ++k)   // sparse phase: work-list sweeps
+      k_shi_list_sweep<<<k < 3 ? 1024 : 256, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_flag, c->wl[3].as<int8_t>(), c->wl_ntaps,
+                                                                  (k & 1) ? list1 : list0, counts + k, (k & 1) ? list0 : list1, counts + k + 1);
+    // tail: the remaining sweeps inside one workgroup
+    k_shi_list_tail<<<1, 1024, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_flag, c->wl[3].as<int8_t>(), c->wl_ntaps,
+                                               (SHI_LIST_SWEEPS & 1) ? list1 : list0, (SHI_LIST_SWEEPS & 1) ? list0 : list1,
+                                               counts + SHI_LIST_SWEEPS, SHI_TAIL_SWEEPS);
   }
   k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_rows_all);
   // header in d[1]: [0] max score bits (8 B) | [8] #survivors (4 B) | [12] #candidates (4 B)
@@ -494,6 +657,20 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   SFMX_HIP(c, c->d[5].ensure(n + 64));
   SFMX_HIP(c, c->d[6].ensure(n * 8));             // scores of all candidates, row-major
   SFMX_HIP(c, c->h[2].ensure(64 + (size_t)SPEC * 16));
+  SFMX_HIP(c, c->wl[0].ensure(n * 4));
+  SFMX_HIP(c, c->wl[1].ensure(n * 4));
+  SFMX_HIP(c, c->wl[2].ensure((SHI_LIST_SWEEPS + 2) * sizeof(int)));
+  if (c->wl_md != min_dist) {  // offsets of the open disc dx^2 + dy^2 < min_dist^2 (centre excluded)
+    std::vector<int8_t> taps;
+    for (int dy = -(min_dist - 1); dy <= min_dist - 1; ++dy)
+      for (int dx = -(min_dist - 1); dx <= min_dist - 1; ++dx)
+        if ((dx || dy) && dx * dx + dy * dy < min_dist * min_dist) { taps.push_back((int8_t)dx); taps.push_back((int8_t)dy); }
+    SFMX_HIP(c, c->wl[3].ensure(taps.size() + 16));
+    SFMX_HIP(c, hipMemcpyAsync(c->wl[3].p, taps.data(), taps.size(), hipMemcpyHostToDevice, c->stream));
+    SFMX_HIP(c, hipStreamSynchronize(c->stream));
+    c->wl_ntaps = (int)taps.size() / 2;
+    c->wl_md = min_dist;
+  }
   uint32_t* d_xy = c->d[3].as<uint32_t>();
   int32_t* d_full = reinterpret_cast<int32_t*>(d_xy + cap);
 
@@ -501,7 +678,7 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   ShiGraphKey key;
   memset(&key, 0, sizeof key);
   key.img = p->base; key.d0 = c->d[0].p; key.d1 = c->d[1].p; key.d2 = c->d[2].p; key.d3 = c->d[3].p; key.d4 = c->d[4].p;
-  key.d5 = c->d[5].p; key.d6 = c->d[6].p; key.pin = c->h[2].p; key.w = p->w; key.h = p->h; key.md = min_dist; key.cap = cap;
+  key.d5 = c->d[5].p; key.d6 = c->d[6].p; key.pin = c->h[2].p; key.w0 = c->wl[0].p; key.w1 = c->wl[1].p; key.w2 = c->wl[2].p; key.w3 = c->wl[3].p; key.w = p->w; key.h = p->h; key.md = min_dist; key.cap = cap;
   key.quality = quality;
   bool launched = false;
   if (!no_graph && !c->timing) {

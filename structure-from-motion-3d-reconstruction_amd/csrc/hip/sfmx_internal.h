@@ -66,6 +66,8 @@ struct sfmx_ctx {
   PinBuf h[4];
   int resident_points = 0;  // #correspondences left in d[0]/d[1] by the last RANSAC call
   int shi_full_count = 0;   // #candidate scores left in d[6] by the last pruned Shi-Tomasi call
+  DevBuf wl[4];             // Shi-Tomasi work lists (2), sweep counters, disc offset table
+  int wl_md = 0, wl_ntaps = 0;
 };
 
 struct sfmx_pyramid {
