@@ -33,30 +33,32 @@
 #define KLT_MAX_R 7
 #define KLT_MAX_NPIX ((2 * KLT_MAX_R + 1) * (2 * KLT_MAX_R + 1))
 
-struct Tap {   // one coordinate of a bilinear sample: integer base, fraction, in-image flag
-  int i0;
-  double f;
-  bool ok;
+struct Tap {   // one coordinate of a bilinear sample: clamped window index, fraction, in-image mask
+  int l;       // index inside the staged window (clamped to [0, KLT_P-2])
+  double f;    // fractional part (0 when the tap is outside the image, so every lerp stays finite)
+  double m;    // 1.0 inside the image, 0.0 outside
 };
-__device__ __forceinline__ Tap make_tap(double v, int extent) {
+__device__ __forceinline__ Tap make_tap(double v, int extent, int origin) {
   Tap t;
-  t.i0 = sfmx::floor_to_int_x86(v);
-  t.f = v - (double)t.i0;
-  t.ok = (t.i0 >= 0) && (t.i0 < extent - 1);  // x0 >= 0 && x0+1 < w   (T:188)
+  const int i0 = sfmx::floor_to_int_x86(v);
+  const bool ok = (i0 >= 0) && (i0 < extent - 1);  // x0 >= 0 && x0+1 < w   (T:188)
+  t.f = ok ? v - (double)i0 : 0.0;
+  t.m = ok ? 1.0 : 0.0;
+  t.l = min(max(i0 - origin, 0), KLT_P - 2);       // inside the staged window by construction when ok
   return t;
 }
-// T:183-198 on the staged window (ox,oy = window origin in image coordinates)
+// T:183-198 on the staged window, branch-free: the four pixels are always read (clamped address) and the
+// in-image test multiplies the result by 1.0 or 0.0 -- exact (v is finite and >= 0), and it keeps the
+// loads unconditional so that the reads of all six samples of a pixel are issued back to back (a
+// `cond ? v : 0` select is turned back into a branch around the loads by the compiler).
 template <int KLT_PS>
-__device__ __forceinline__ double sample_lds(const float* __restrict__ win, int ox, int oy, const Tap& cx, const Tap& cy) {
-  if (!(cx.ok && cy.ok)) return 0.0;
-  int lx = cx.i0 - ox, ly = cy.i0 - oy;
-  lx = min(max(lx, 0), KLT_P - 2);  // defensive: never leaves the window (ensure_window guarantees it)
-  ly = min(max(ly, 0), KLT_P - 2);
-  const float* p = win + ly * KLT_PS + lx;
+__device__ __forceinline__ double sample_lds(const float* __restrict__ win, const Tap& cx, const Tap& cy) {
+  const float* p = win + cy.l * KLT_PS + cx.l;
   const double v00 = (double)p[0], v10 = (double)p[1], v01 = (double)p[KLT_PS], v11 = (double)p[KLT_PS + 1];
   const double v0 = v00 * (1 - cx.f) + v10 * cx.f;
   const double v1 = v01 * (1 - cx.f) + v11 * cx.f;
-  return v0 * (1 - cy.f) + v1 * cy.f;
+  const double v = v0 * (1 - cy.f) + v1 * cy.f;
+  return v * (cx.m * cy.m);
 }
 
 // Both windows are staged together: all 32 byte loads of a lane are issued before the first LDS
@@ -143,7 +145,14 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         // ---- make sure the staged window covers the footprint [b-r-2, b+r+3] of this step
         const int bx = book_floor(x), by = book_floor(y);
         const bool touches = (bx + r + 3 >= 0) && (bx - r - 2 < w) && (by + r + 3 >= 0) && (by - r - 2 < h);
-        if (touches) {
+        if (!touches) {
+          // Every sample of this step is 0.0 in the reference (T:188) => A = 0, detA = 0 => step {0,0} (T:452)
+          // => hypot(0,0) < 1e-3 ends the level (T:416).  Nothing to read: the window may be unstaged, and
+          // stale LDS bits must never reach the mask-multiply in sample_lds (NaN * 0 = NaN).
+          ++steps;
+          break;
+        }
+        {
           const bool covered = (bx - r - 2 >= ox) && (bx + r + 3 < ox + KLT_P) && (by - r - 2 >= oy) && (by + r + 3 < oy + KLT_P);
           if (!covered) {
             ox = bx - (KLT_P / 2 - 1);
@@ -160,12 +169,12 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
           if (pix >= npix) break;
           const int dyi = pix / side - r, dxi = pix % side - r;
           const double xx = x + (double)dxi, yy = y + (double)dyi;
-          const Tap cx0 = make_tap(xx, w), cxp = make_tap(xx + 1, w), cxm = make_tap(xx - 1, w);
-          const Tap cy0 = make_tap(yy, h), cyp = make_tap(yy + 1, h), cym = make_tap(yy - 1, h);
-          const double Ix = 0.5 * (sample_lds<KLT_PS>(win1, ox, oy, cxp, cy0) - sample_lds<KLT_PS>(win1, ox, oy, cxm, cy0));
-          const double Iy = 0.5 * (sample_lds<KLT_PS>(win1, ox, oy, cx0, cyp) - sample_lds<KLT_PS>(win1, ox, oy, cx0, cym));
-          const double Iref = sample_lds<KLT_PS>(win0, ox, oy, cx0, cy0);
-          const double Icur = sample_lds<KLT_PS>(win1, ox, oy, cx0, cy0);
+          const Tap cx0 = make_tap(xx, w, ox), cxp = make_tap(xx + 1, w, ox), cxm = make_tap(xx - 1, w, ox);
+          const Tap cy0 = make_tap(yy, h, oy), cyp = make_tap(yy + 1, h, oy), cym = make_tap(yy - 1, h, oy);
+          const double Ix = 0.5 * (sample_lds<KLT_PS>(win1, cxp, cy0) - sample_lds<KLT_PS>(win1, cxm, cy0));
+          const double Iy = 0.5 * (sample_lds<KLT_PS>(win1, cx0, cyp) - sample_lds<KLT_PS>(win1, cx0, cym));
+          const double Iref = sample_lds<KLT_PS>(win0, cx0, cy0);
+          const double Icur = sample_lds<KLT_PS>(win1, cx0, cy0);
           const double err = Iref - Icur;
           prod[0 * npad + pix] = Ix * Ix;
           prod[1 * npad + pix] = Ix * Iy;
