@@ -39,6 +39,10 @@ int sfmx_ctx_create(int device_id, sfmx_ctx** out);
 void sfmx_ctx_destroy(sfmx_ctx* ctx);
 const char* sfmx_last_error(const sfmx_ctx* ctx);
 int sfmx_sync(sfmx_ctx* ctx);
+int sfmx_ctx_device(const sfmx_ctx* ctx);  /* device index the context was created on */
+/* HIP's current device is per host thread: a thread that did not create the context calls this once before
+ * using it (one context per thread; contexts of several threads may share a device). */
+int sfmx_ctx_make_current(sfmx_ctx* ctx);
 /* raw hipStream_t of the context (for event timing by the caller) */
 void* sfmx_stream(sfmx_ctx* ctx);
 /* microseconds of GPU time of the most recent hot kernel launched by the last API call, measured
@@ -78,9 +82,11 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double qu
 int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* ctx, const sfmx_pyramid* pyr, double quality, int min_dist,
                                       int cap, uint32_t* cand_xy, double* cand_score, int32_t* cand_full_index,
                                       int* n_out, int* n_total_out, double* max_out);
-/* cand_full_index[k] (optional) = position of survivor k in the row-major list of ALL candidates, whose
- * scores stay in HBM until the next Shi-Tomasi / RANSAC call and can be fetched with: */
-int sfmx_shi_tomasi_fetch_all_scores(sfmx_ctx* ctx, int n_total, double* scores_out);
+/* cand_full_index[k] (optional) = position of survivor k in the row-major list of ALL candidates.  That list
+ * is kept as 16-byte records {double score; uint32 id (= position); uint32 mark (= 0)} and is downloaded
+ * speculatively into pinned host memory owned by the context; *keys_out stays valid (and may be modified
+ * in place) until the next Shi-Tomasi call on this context. */
+int sfmx_shi_tomasi_fetch_all_keys(sfmx_ctx* ctx, int n_total, void** keys_out);
 
 /* ---- KLT: replaces KLTTracker::track_one fwd+bwd and the FB test (T:356-362, 402-460) ------- */
 typedef struct sfmx_klt_cfg {

@@ -23,6 +23,7 @@ int sfmx_ctx_create(int device_id, sfmx_ctx** out) {
   sfmx_ctx* c = new sfmx_ctx;
   c->device = device_id;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return SFMX_ERR_HIP;
@@ -35,12 +36,15 @@ void sfmx_ctx_destroy(sfmx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  sfmx_release_graphs(c);
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   for (auto& b : c->d) b.release();
   for (auto& b : c->wl) b.release();
   for (auto& b : c->h) b.release();
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   delete c;
 }
 
@@ -49,6 +53,12 @@ const char* sfmx_last_error(const sfmx_ctx* c) { return c ? c->err.c_str() : "nu
 int sfmx_sync(sfmx_ctx* c) {
   if (!c) return SFMX_ERR_INVALID;
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  return SFMX_OK;
+}
+int sfmx_ctx_device(const sfmx_ctx* c) { return c ? c->device : -1; }
+int sfmx_ctx_make_current(sfmx_ctx* c) {
+  if (!c) return SFMX_ERR_INVALID;
+  SFMX_HIP(c, hipSetDevice(c->device));
   return SFMX_OK;
 }
 void* sfmx_stream(sfmx_ctx* c) { return c ? (void*)c->stream : nullptr; }

@@ -7,6 +7,8 @@
 #include "sfmx_internal.h"
 
 #include <cstdlib>
+#include <list>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -469,7 +471,7 @@ __global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* _
 }
 __global__ void k_flag_row_write(const double* __restrict__ score, const uint8_t* __restrict__ flag, int w, const int* __restrict__ row_off,
                                  const int* __restrict__ row_off_all, int cap, uint32_t* __restrict__ cand_xy, double* __restrict__ cand_s,
-                                 int32_t* __restrict__ cand_full, double* __restrict__ all_s) {
+                                 int32_t* __restrict__ cand_full, double2* __restrict__ all_keys) {
   const int y = blockIdx.x;
   int off = row_off[y], offa = row_off_all[y];
   for (int base = 0; base < w; base += 64) {
@@ -480,7 +482,7 @@ __global__ void k_flag_row_write(const double* __restrict__ score, const uint8_t
     const unsigned long long below = (1ull << threadIdx.x) - 1ull;
     const int posa = offa + __popcll(ma & below);
     const double s = any ? score[(size_t)y * w + x] : 0.0;
-    if (any) all_s[posa] = s;
+    if (any) all_keys[posa] = make_double2(s, __hiloint2double(0, posa));  // {score, (id = posa, mark = 0)}: the host's SortKey
     if (hit) {
       const int pos = off + __popcll(m & below);
       if (pos < cap) {
@@ -576,11 +578,23 @@ struct ShiGraphKey {
   bool operator==(const ShiGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
 };
 struct ShiGraph { ShiGraphKey key; hipGraphExec_t exec; };
+// per-context caches live in one registry; contexts belong to different host threads, hence the lock
+static std::mutex g_graph_mu;
+static std::list<std::pair<sfmx_ctx*, std::vector<ShiGraph>>> g_graph_registry;
 static std::vector<ShiGraph>& shi_graphs(sfmx_ctx* c) {
-  static std::vector<std::pair<sfmx_ctx*, std::vector<ShiGraph>>> all;
-  for (auto& e : all) if (e.first == c) return e.second;
-  all.emplace_back(c, std::vector<ShiGraph>());
-  return all.back().second;
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  for (auto& e : g_graph_registry) if (e.first == c) return e.second;
+  g_graph_registry.emplace_back(c, std::vector<ShiGraph>());
+  return g_graph_registry.back().second;  // std::list: the reference stays valid when other contexts register
+}
+void sfmx_release_graphs(sfmx_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  for (auto it = g_graph_registry.begin(); it != g_graph_registry.end(); ++it)
+    if (it->first == c) {
+      for (auto& g : it->second) (void)hipGraphExecDestroy(g.exec);
+      g_graph_registry.erase(it);
+      return;
+    }
 }
 #define SHI_SPEC 4096
 #define SHI_TILED_SWEEPS 5
@@ -628,7 +642,7 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_tot);
   k_row_scan<<<1, 64, 0, c->stream>>>(d_rows_all, p->h, d_tot + 1);
   k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, d_rows_all, cap, d_xy, c->d[4].as<double>(), d_full,
-                                          c->d[6].as<double>());
+                                          c->d[6].as<double2>());
   SFMX_HIP(c, hipGetLastError());
   // the 16-byte header plus a speculative download of the first SPEC survivors (there are ~1.5-2 k per
   // VGA frame) through pinned memory; a second trip happens only if there are more
@@ -648,6 +662,10 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   const size_t n = (size_t)p->w * p->h;
   c->resident_points = 0;
   c->shi_full_count = 0;
+  if (c->shi_keys_in_flight) {
+    SFMX_HIP(c, hipStreamSynchronize(c->copy_stream));
+    c->shi_keys_in_flight = false;
+  }
   const int SPEC = cap < SHI_SPEC ? cap : SHI_SPEC;
   SFMX_HIP(c, c->d[0].ensure(n * 8));
   SFMX_HIP(c, c->d[1].ensure(64));
@@ -655,7 +673,7 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   SFMX_HIP(c, c->d[3].ensure((size_t)cap * 8));   // xy (u32) + full index (i32)
   SFMX_HIP(c, c->d[4].ensure((size_t)cap * 8));
   SFMX_HIP(c, c->d[5].ensure(n + 64));
-  SFMX_HIP(c, c->d[6].ensure(n * 8));             // scores of all candidates, row-major
+  SFMX_HIP(c, c->d[6].ensure(n * 16));            // sort keys {score, id, mark} of all candidates, row-major
   SFMX_HIP(c, c->h[2].ensure(64 + (size_t)SPEC * 16));
   SFMX_HIP(c, c->wl[0].ensure(n * 4));
   SFMX_HIP(c, c->wl[1].ensure(n * 4));
@@ -735,17 +753,26 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   *n_out = tot;
   if (n_total_out) *n_total_out = tot_all;
   if (max_out) *max_out = mx;
+  // Speculative download of the full key list (2 MB per VGA frame) on the copy stream: most frames need it for
+  // the tie-order replay, and it overlaps with the host's sort + walk over the survivors.
+  if (tot_all > 0) {
+    SFMX_HIP(c, c->h[3].ensure((size_t)tot_all * 16));
+    SFMX_HIP(c, hipMemcpyAsync(c->h[3].p, c->d[6].p, (size_t)tot_all * 16, hipMemcpyDeviceToHost, c->copy_stream));
+    c->shi_keys_in_flight = true;
+  }
   return SFMX_OK;
 }
 
 // scores of ALL candidates (row-major) of the preceding sfmx_shi_tomasi_candidates_pruned call, still in HBM
-int sfmx_shi_tomasi_fetch_all_scores(sfmx_ctx* c, int n_total, double* scores_out) {
-  SFMX_REQUIRE(c, c && scores_out && n_total > 0 && n_total == c->shi_full_count);
-  const size_t nb = (size_t)n_total * 8;
-  SFMX_HIP(c, c->h[1].ensure(nb));
-  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, c->d[6].p, nb, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipStreamSynchronize(c->stream));
-  memcpy(scores_out, c->h[1].p, nb);
+int sfmx_shi_tomasi_fetch_all_keys(sfmx_ctx* c, int n_total, void** keys_out) {
+  SFMX_REQUIRE(c, c && keys_out && n_total > 0 && n_total == c->shi_full_count);
+  if (!c->shi_keys_in_flight) {
+    SFMX_HIP(c, c->h[3].ensure((size_t)n_total * 16));
+    SFMX_HIP(c, hipMemcpyAsync(c->h[3].p, c->d[6].p, (size_t)n_total * 16, hipMemcpyDeviceToHost, c->copy_stream));
+  }
+  SFMX_HIP(c, hipStreamSynchronize(c->copy_stream));
+  c->shi_keys_in_flight = false;
+  *keys_out = c->h[3].p;  // pinned host memory owned by the context; valid until the next Shi-Tomasi call
   return SFMX_OK;
 }
 

@@ -221,48 +221,57 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
     for (int e = t; e < 81; e += HG) L.V[e] = (e / 9 == e % 9) ? 1.0 : 0.0;
   }
   __syncthreads();
-  // ---- 9x9 Jacobi (linalg.hpp:141-186)
-  // Every lane of the group scans the 36 upper-triangle entries itself (LDS broadcast reads, strict
-  // '>' in row-major order = the reference's first-maximum rule), so no cross-lane reduction and no
-  // index decoding sits on the per-rotation critical path.
+  // ---- 9x9 Jacobi (linalg.hpp:141-186): same pivot rule (first maximum of |a_ij|, i<j, row-major), same
+  // rotation angle, same sweep cap.  The similarity transform A <- J^T A J is applied in its symmetric
+  // one-pass form (off-diagonal pairs rotated and mirrored, 2x2 pivot block in closed form) instead of the
+  // reference's row pass followed by a column pass: mathematically identical, two LDS round trips per
+  // rotation instead of five.  These E's only RANK hypotheses (the winner is re-derived with libm on the
+  // host), so last-bit differences from the reference's evaluation order are irrelevant here.
+  // Every lane of the group scans the 36 upper-triangle entries itself (LDS broadcast reads).
   bool active = live;
   for (int it = 0; it < sweeps; ++it) {
     double bv = 0.0;
     int p = 0, q = 1;
     if (active) {
+      double u[36];
+      int n = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) u[n++] = fabs(L.A[i * 9 + j]);
+      n = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = i + 1; j < 9; j++) {
-          const double v = fabs(L.A[i * 9 + j]);
-          if (v > bv) { bv = v; p = i; q = j; }  // NaN never wins, as in the reference's `v > maxv`
+          if (u[n] > bv) { bv = u[n]; p = i; q = j; }  // NaN never wins, as in the reference's `v > maxv`
+          n++;
         }
     }
     if (active && bv < 1e-12) active = false;  // maxv < 1e-12 -> break
     if (!__any(active)) break;
-    Rot r;
-    r.c = 1.0; r.s = 0.0;
-    if (active) r = half_angle_fast(2.0 * L.A[p * 9 + q], L.A[q * 9 + q] - L.A[p * 9 + p]);
-    const double c = r.c, s = r.s;
-    __syncthreads();
-    if (active && t < 9) {  // rows p,q
-      const double ap = L.A[p * 9 + t], aq = L.A[q * 9 + t];
-      L.A[p * 9 + t] = c * ap - s * aq;
-      L.A[q * 9 + t] = s * ap + c * aq;
-    }
-    __syncthreads();
-    if (active && t < 9) {  // columns p,q on the row-updated matrix, and the eigenvector columns
-      const double ap = L.A[t * 9 + p], aq = L.A[t * 9 + q];
-      const double vp = L.V[t * 9 + p], vq = L.V[t * 9 + q];
-      L.A[t * 9 + p] = c * ap - s * aq;
-      L.A[t * 9 + q] = s * ap + c * aq;
-      L.V[t * 9 + p] = c * vp - s * vq;
-      L.V[t * 9 + q] = s * vp + c * vq;
-    }
-    __syncthreads();
-    if (active && t == 0) {
-      L.A[p * 9 + q] = 0.0;
-      L.A[q * 9 + p] = 0.0;
+    if (active) {
+      const double app = L.A[p * 9 + p], aqq = L.A[q * 9 + q], apq = L.A[p * 9 + q];
+      const Rot r = half_angle_fast(2.0 * apq, aqq - app);
+      const double c = r.c, s = r.s;
+      if (t < 9) {
+        const double vp = L.V[t * 9 + p], vq = L.V[t * 9 + q];
+        const double akp = L.A[t * 9 + p], akq = L.A[t * 9 + q];
+        L.V[t * 9 + p] = c * vp - s * vq;
+        L.V[t * 9 + q] = s * vp + c * vq;
+        if (t != p && t != q) {
+          const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+          L.A[t * 9 + p] = np_; L.A[p * 9 + t] = np_;
+          L.A[t * 9 + q] = nq_; L.A[q * 9 + t] = nq_;
+        } else if (t == p) {
+          // J = [[c, s], [-s, c]] on (p,q): a_pp' = c^2 app - 2cs apq + s^2 aqq, a_qq' = s^2 app + 2cs apq + c^2 aqq
+          const double cc = c * c, ss = s * s, cs2 = 2.0 * c * s * apq;
+          L.A[p * 9 + p] = cc * app - cs2 + ss * aqq;
+          L.A[q * 9 + q] = ss * app + cs2 + cc * aqq;
+          L.A[p * 9 + q] = 0.0;
+          L.A[q * 9 + p] = 0.0;
+        }
+      }
     }
     __syncthreads();
   }

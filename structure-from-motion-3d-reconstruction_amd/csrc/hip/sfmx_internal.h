@@ -57,15 +57,17 @@ struct PinBuf {
 struct sfmx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // speculative D2H that must not delay the compute stream
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   double last_us = 0.0;
   std::string err;
   // reusable staging: a few independent device / pinned slabs
   DevBuf d[8];
-  PinBuf h[4];
+  PinBuf h[5];
   int resident_points = 0;  // #correspondences left in d[0]/d[1] by the last RANSAC call
   int shi_full_count = 0;   // #candidate scores left in d[6] by the last pruned Shi-Tomasi call
+  bool shi_keys_in_flight = false;
   DevBuf wl[4];             // Shi-Tomasi work lists (2), sweep counters, disc offset table
   int wl_md = 0, wl_ntaps = 0;
 };
@@ -97,6 +99,7 @@ static inline PyrDesc make_desc(const sfmx_pyramid* p) {
 }
 
 int sfmx_fail(sfmx_ctx* ctx, int status, const char* what, hipError_t e);
+extern "C" void sfmx_release_graphs(sfmx_ctx* ctx);  // image.hip: drop the hipGraph executables cached for this context
 
 #define SFMX_HIP(ctx, call)                                                         \
   do {                                                                              \

@@ -19,6 +19,7 @@
 // real std::sort on tie-heavy inputs, and the selective replay against the full one.
 #pragma once
 #include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -92,12 +93,13 @@ inline long lg(long n) { long k = 0; while (n > 1) { n >>= 1; ++k; } return k; }
 // Selective replay.  On success, keys[] is in "end of loop phase" arrangement along the followed
 // paths: comparing the array positions of two marked elements of equal score gives their order in
 // the real std::sort output.  Returns false when the replay has to give up (depth limit).
-inline bool introsort_replay_selective(std::vector<SortKey>& keys) {
-  if (keys.size() < 2) return true;
-  const int marked = introsort_detail::count_marked(keys.data(), keys.data() + keys.size());
+inline bool introsort_replay_selective(SortKey* keys, std::size_t n) {
+  if (n < 2) return true;
+  const int marked = introsort_detail::count_marked(keys, keys + n);
   if (marked < 2) return true;
-  return introsort_detail::loop(keys.data(), keys.data() + keys.size(), 2 * introsort_detail::lg((long)keys.size()), true, marked);
+  return introsort_detail::loop(keys, keys + n, 2 * introsort_detail::lg((long)n), true, marked);
 }
+inline bool introsort_replay_selective(std::vector<SortKey>& keys) { return introsort_replay_selective(keys.data(), keys.size()); }
 
 // Full replay: must reproduce std::sort exactly (used by the tests to pin the replica).
 inline bool introsort_replay_full(std::vector<SortKey>& keys) {

@@ -22,7 +22,7 @@ using Clock = std::chrono::steady_clock;
 inline double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
 void check(sfmx_ctx* ctx, int rc, const char* where) {
-  if (rc != SFMX_OK) throw SfmxFailure(rc, std::string("sfmx: ") + where + ": " + sfmx_last_error(ctx));
+  if (rc != SFMX_OK) throw SfmxFailure(rc, std::string("sfmx: ") + where + ": " + (ctx ? sfmx_last_error(ctx) : "no context"));
 }
 }  // namespace
 
@@ -35,7 +35,7 @@ void MemoryFrames::load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) {
 
 // ------------------------------------------------------------------------------------------ tracker
 GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk)
-    : ctx_(ctx), cfg_(cfg), w_(w), h_(h), clk_(clk) {
+    : ctx_(ctx), cfg_(cfg), w_(w), h_(h), clk_(clk), det_(ctx, clk) {
   levels_total_ = std::max(cfg.pyr_levels, extra_levels);
   check(ctx_, sfmx_pyramid_create(ctx_, w, h, levels_total_, &prev_), "pyramid_create");
   check(ctx_, sfmx_pyramid_create(ctx_, w, h, levels_total_, &cur_), "pyramid_create");
@@ -45,7 +45,42 @@ GpuTracker::~GpuTracker() {
   sfmx_pyramid_destroy(ctx_, cur_);
 }
 
-std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist) {
+std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist, int frame_key) {
+  const auto t0 = Clock::now();
+  if (clk_) clk_->shi_calls++;
+  auto prefix = [&](const std::vector<V2>& cc) { return std::vector<V2>(cc.begin(), cc.begin() + (long)std::min((size_t)std::max(max_corners, 0), cc.size())); };
+  if (frame_key >= 0 && max_corners >= 1) {
+    auto it = corner_cache_.find(frame_key);
+    if (it != corner_cache_.end() && it->second.quality == quality && it->second.min_dist == min_dist &&
+        (it->second.exhausted || max_corners <= it->second.cap)) {
+      if (clk_) clk_->shi_memo_hits++;
+      return prefix(it->second.corners);
+    }
+    if (prefetch_ && prefetch_->matches(quality, min_dist)) {  // computed ahead of time on the worker's context?
+      std::vector<V2> seq;
+      const auto tw = Clock::now();
+      const bool ok = prefetch_->take(frame_key, seq);
+      if (clk_) clk_->shi_wait += since(tw);
+      if (ok) {
+        if (clk_) clk_->shi_prefetched++;
+        if (corner_cache_.size() >= 4096) corner_cache_.erase(corner_cache_.begin());
+        auto& m = corner_cache_[frame_key];
+        m = CornerMemo{quality, min_dist, 0x7fffffff, true, std::move(seq)};
+        if (clk_) clk_->shi += since(t0);
+        return prefix(m.corners);
+      }
+    }
+  }
+  std::vector<V2> out = det_.detect(pyr, max_corners, quality, min_dist);
+  if (frame_key >= 0 && max_corners >= 1) {
+    if (corner_cache_.size() >= 4096) corner_cache_.erase(corner_cache_.begin());  // bound the memo on very long runs
+    corner_cache_[frame_key] = CornerMemo{quality, min_dist, max_corners, (int)out.size() < max_corners, out};
+  }
+  if (clk_) clk_->shi += since(t0);
+  return out;
+}
+
+std::vector<V2> CornerDetector::detect(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist) {
   const auto t0 = Clock::now();
   int w = 0, h = 0;
   sfmx_pyramid_level_size(pyr, 0, &w, &h);
@@ -123,16 +158,16 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
       // ---- tie order from a selective replay of libstdc++'s introsort on the FULL candidate list
       if (clk_) clk_->shi_fallbacks++;
       const auto tr0 = Clock::now();
-      // the scores of ALL candidates are still resident in HBM; survivors know their index in that list
+      // The sort keys of ALL candidates were downloaded speculatively into pinned memory by the device call;
+      // survivors know their index in that list.  The replay runs in place on that buffer.
       const int nf = n_total;
-      if ((int)all_s_.size() < nf) all_s_.resize((size_t)nf);
-      check(ctx_, sfmx_shi_tomasi_fetch_all_scores(ctx_, nf, all_s_.data()), "shi_tomasi_fetch_all_scores");
+      void* kp = nullptr;
+      check(ctx_, sfmx_shi_tomasi_fetch_all_keys(ctx_, nf, &kp), "shi_tomasi_fetch_all_keys");
+      static_assert(sizeof(SortKey) == 16, "SortKey must match the device record {double, u32, u32}");
+      SortKey* keys = static_cast<SortKey*>(kp);
       std::vector<Cand> pruned((size_t)n);
       for (int k = 0; k < n; k++)
         pruned[(size_t)k] = {(int)(cand_xy_[(size_t)k] & 0x7fffu), (int)((cand_xy_[(size_t)k] >> 16) & 0x7fffu), cand_s_[(size_t)k], k};
-      std::vector<SortKey>& keys = keys_;  // persistent: a fresh 2 MB vector per call costs more than the replay
-      keys.resize((size_t)nf);
-      for (int f = 0; f < nf; f++) keys[(size_t)f] = SortKey{all_s_[(size_t)f], (std::uint32_t)f, 0u};
       // interesting = survivors that share their score with another survivor
       for (size_t a = 0; a + 1 < cands.size(); a++)
         if (cands[a].s == cands[a + 1].s) {
@@ -140,14 +175,15 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
           keys[(size_t)cand_full_[(size_t)cands[a + 1].idx]].mark = 1;
         }
       const std::vector<std::int32_t>& full_of = cand_full_;
-      if (introsort_replay_selective(keys)) {
-        std::vector<int>& pos = pos_;
-        pos.resize((size_t)nf);
-        for (int f = 0; f < nf; f++) pos[(size_t)keys[(size_t)f].id] = f;
+      if (introsort_replay_selective(keys, (size_t)nf)) {
+        // positions of the marked elements after the replay (only those are ever compared)
+        std::unordered_map<int, int> pos;
+        for (int f = 0; f < nf; f++)
+          if (keys[(size_t)f].mark) pos.emplace((int)keys[(size_t)f].id, f);
         cands = pruned;
         std::sort(cands.begin(), cands.end(), [&](const Cand& a, const Cand& b) {
           if (a.s != b.s) return a.s > b.s;
-          return pos[(size_t)full_of[(size_t)a.idx]] < pos[(size_t)full_of[(size_t)b.idx]];
+          return pos.at(full_of[(size_t)a.idx]) < pos.at(full_of[(size_t)b.idx]);  // equal scores => both are marked
         });
         out.clear();
         next.clear();
@@ -180,8 +216,89 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
       if ((int)out.size() >= max_corners) break;
     }
   }
-  if (clk_) clk_->shi += since(t0);
   return out;
+}
+
+// ------------------------------------------------------------------------------------------ prefetcher
+CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist)
+    : src_(src), quality_(quality), min_dist_(min_dist) {
+  check(nullptr, sfmx_ctx_create(device, &ctx_), "ctx_create(prefetch)");
+  try {
+    check(ctx_, sfmx_pyramid_create(ctx_, src.width(), src.height(), 1, &pyr_), "pyramid_create(prefetch)");
+  } catch (...) {
+    sfmx_ctx_destroy(ctx_);
+    throw;
+  }
+  det_ = std::make_unique<CornerDetector>(ctx_, &clock);
+  th_ = std::thread([this] { run(); });
+}
+CornerPrefetcher::~CornerPrefetcher() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_req_.notify_all();
+  if (th_.joinable()) th_.join();
+  det_.reset();
+  sfmx_pyramid_destroy(ctx_, pyr_);
+  sfmx_ctx_destroy(ctx_);
+}
+void CornerPrefetcher::request(int frame) {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (frame < 0 || frame >= src_.count() || slots_.count(frame)) return;
+    slots_.emplace(frame, Slot{});
+    queue_.push_back(frame);
+  }
+  cv_req_.notify_one();
+}
+void CornerPrefetcher::discard_older_than(int frame) {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (auto it = slots_.begin(); it != slots_.end();)
+    if (it->first < frame && it->second.done) it = slots_.erase(it);
+    else ++it;
+}
+bool CornerPrefetcher::take(int frame, std::vector<V2>& corners) {
+  std::unique_lock<std::mutex> lk(mu_);
+  auto it = slots_.find(frame);
+  if (it == slots_.end()) return false;
+  cv_done_.wait(lk, [&] { return slots_.at(frame).done; });
+  Slot& s = slots_.at(frame);
+  const bool ok = !s.failed;
+  if (ok) corners = std::move(s.corners);
+  slots_.erase(frame);
+  return ok;
+}
+void CornerPrefetcher::run() {
+  (void)sfmx_ctx_make_current(ctx_);  // HIP's current device is per thread
+  for (;;) {
+    int frame;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_req_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+      if (stop_) return;
+      frame = queue_.front();
+      queue_.pop_front();
+    }
+    std::vector<V2> seq;
+    bool failed = false;
+    try {
+      src_.load(ctx_, frame, pyr_);
+      seq = det_->detect(pyr_, 0x3fffffff, quality_, min_dist_);  // uncapped: every later request is a prefix
+    } catch (...) {
+      failed = true;  // the main thread recomputes synchronously and reports the error where the reference would
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = slots_.find(frame);
+      if (it != slots_.end()) {
+        it->second.corners = std::move(seq);
+        it->second.failed = failed;
+        it->second.done = true;
+      }
+    }
+    cv_done_.notify_all();
+  }
 }
 
 void GpuTracker::reset(FrameSource& src, int fi) {
@@ -190,7 +307,7 @@ void GpuTracker::reset(FrameSource& src, int fi) {
   if (clk_) clk_->upload += since(t0);
   have_prev_ = true;
   tracks_.clear();
-  for (const V2& p : shi_tomasi(prev_, cfg_.max_tracks, cfg_.quality, cfg_.min_distance)) tracks_.push_back({next_id_++, p});
+  for (const V2& p : shi_tomasi(prev_, cfg_.max_tracks, cfg_.quality, cfg_.min_distance, fi)) tracks_.push_back({next_id_++, p});
 }
 
 void GpuTracker::track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
@@ -242,7 +359,7 @@ StepOut GpuTracker::step(FrameSource& src, int fi) {
   tracks_ = std::move(kept);
   if ((int)tracks_.size() < cfg_.min_tracks) {  // replenish (T:374-389)
     const int need = cfg_.max_tracks - (int)tracks_.size();
-    const auto pts = shi_tomasi(prev_, need * 3, cfg_.quality, cfg_.min_distance);
+    const auto pts = shi_tomasi(prev_, need * 3, cfg_.quality, cfg_.min_distance, fi);
     t0 = Clock::now();
     // distance filter against all live tracks (incl. the ones appended here): existence test, so a
     // grid over track positions gives the same answer as the reference's linear scan.
@@ -568,6 +685,11 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   const int dlevel = desc_level(w, h);
   if (dlevel + 1 > 8 || cfg.klt.pyr_levels > 8) throw SfmxFailure(SFMX_ERR_UNSUPPORTED, "image too large for an 8-level pyramid");
   GpuTracker tracker(ctx, cfg.klt, w, h, dlevel + 1, &clk);
+  std::unique_ptr<CornerPrefetcher> prefetch;
+  if (!std::getenv("SFMX_NO_PREFETCH") && std::min(cfg.frames, src.count()) > 1 && cfg.klt.min_distance >= 1 && cfg.klt.min_distance <= 16) {
+    prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance);
+    tracker.set_prefetcher(prefetch.get());
+  }
   GpuBundleAdjuster ba(ctx, &clk);
   sfmx_pyramid* old_pyr = nullptr;  // loop-closure verification image (T:1834)
   struct Guard { sfmx_ctx* c; sfmx_pyramid** p; ~Guard() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard{ctx, &old_pyr};
@@ -591,6 +713,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   };
 
   for (int fi = 0; fi < std::min(frames, src.count()); ++fi) {
+    if (prefetch) {
+      prefetch->discard_older_than(fi);  // results nobody asked for (no replenish on that frame)
+      if (fi + 1 < std::min(frames, src.count())) prefetch->request(fi + 1);  // overlaps with this frame's work
+    }
     StepOut step = tracker.step(src, fi);
     if (step.prev_pts.empty()) {  // first keyframe (T:1715-1733)
       Keyframe kf(arena);
@@ -717,7 +843,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         LKConfig lc = cfg.klt;
         lc.max_tracks = 1200;
         lc.min_tracks = 600;
-        const auto pts0 = tracker.shi_tomasi(old_pyr, lc.max_tracks, lc.quality, lc.min_distance);
+        const auto pts0 = tracker.shi_tomasi(old_pyr, lc.max_tracks, lc.quality, lc.min_distance, old_kf.frame_idx);
         std::vector<V2> fwd;
         std::vector<std::uint8_t> keep;
         tracker.track_pairs(old_pyr, tracker.current(), pts0, fwd, keep);
@@ -737,9 +863,15 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         }
       }
     }
+    if (!make_kf) tracker.forget_corners(fi);  // only keyframe images are ever re-detected (loop closure)
     emit(fi);
   }
   out.log = so.str();
+  if (prefetch) {
+    tracker.set_prefetcher(nullptr);
+    clk.shi_fallbacks += prefetch->clock.shi_fallbacks;  // the worker's tie-order replays count too
+    prefetch.reset();
+  }
   clk.total = since(t_all);
 }
 
@@ -803,7 +935,8 @@ struct sfmx_pipeline_stats {
   int n_keyframes, n_points, n_edges, n_frames;
   double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host, sec_shi_gpu, sec_shi_replay, sec_desc, sec_bookkeeping, sec_r_pre, sec_r_gpu, sec_r_verify, sec_r_decomp, sec_tri_iter, sec_tri_solve, sec_tri_insert;
   double us_klt_kernel, us_ransac_kernel, us_ba_kernel, us_shi_kernel;
-  unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks;
+  unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks, shi_calls, shi_memo_hits, shi_prefetched;
+  double sec_shi_wait;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -846,7 +979,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
       *stats = sfmx_pipeline_stats{(int)res.kfs.size(), (int)res.map.pts.size(), (int)res.edges.size(), std::min(pc.frames, n_images),
                                    c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host, c.shi_gpu, c.shi_replay, c.desc, c.bookkeeping, c.r_pre, c.r_gpu, c.r_verify, c.r_decomp, c.tri_iter, c.tri_solve, c.tri_insert,
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
-                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks};
+                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait};
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {

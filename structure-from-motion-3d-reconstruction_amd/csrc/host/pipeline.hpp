@@ -3,8 +3,13 @@
 // the sfmx C ABI, plus the per-frame loop of main() (T:1686-1911) and its CSV/PLY writers.
 // Nothing here falls back to CPU arithmetic for the hot kernels: a failing C-ABI call is an error.
 #pragma once
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <optional>
+#include <thread>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -62,7 +67,56 @@ struct StageClock {
   double r_pre = 0, r_gpu = 0, r_verify = 0, r_decomp = 0, tri_iter = 0, tri_solve = 0, tri_insert = 0;
   double klt_kernel_us = 0, ransac_kernel_us = 0, ba_kernel_us = 0, shi_kernel_us = 0;
   std::uint64_t lk_steps = 0, tracks_in = 0, ransac_calls = 0, ransac_points = 0, ba_calls = 0, ba_iters = 0, klt_calls = 0;
-  std::uint64_t ransac_verified = 0, shi_fallbacks = 0;
+  std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
+  double shi_wait = 0;
+};
+
+// shi_tomasi (T:237-302) on one context: device score + certain-outcome fixpoint (sfmx_shi_tomasi_candidates_pruned),
+// then the reference's sort + greedy min-distance pick on the few surviving candidates (tie order via the
+// introsort replay when needed).  One detector per context / per thread.
+class CornerDetector {
+ public:
+  CornerDetector(sfmx_ctx* ctx, StageClock* clk) : ctx_(ctx), clk_(clk) {}
+  std::vector<V2> detect(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist);
+
+ private:
+  sfmx_ctx* ctx_;
+  StageClock* clk_;
+  std::vector<std::uint32_t> cand_xy_;
+  std::vector<double> cand_s_;
+  std::vector<std::int32_t> cand_full_;
+};
+
+// Corner detection of frame f+1 depends only on image f+1, so it is computed ahead of time by a worker thread
+// with its OWN sfmx context (own HIP stream and buffers) while the main thread tracks / scores / adjusts frame f.
+// The result is the uncapped accepted-corner sequence; GpuTracker::shi_tomasi takes prefixes of it.
+class CornerPrefetcher {
+ public:
+  CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist);
+  ~CornerPrefetcher();
+  CornerPrefetcher(const CornerPrefetcher&) = delete;
+  CornerPrefetcher& operator=(const CornerPrefetcher&) = delete;
+  void request(int frame);                          // non-blocking; ignored if already requested
+  bool take(int frame, std::vector<V2>& corners);   // waits for a requested frame; false if never requested / failed
+  void discard_older_than(int frame);               // drop finished results of frames < frame that nobody took
+  bool matches(double quality, int min_dist) const { return quality == quality_ && min_dist == min_dist_; }
+  StageClock clock;                                 // the worker's own counters (read after the run)
+
+ private:
+  void run();
+  struct Slot { bool done = false, failed = false; std::vector<V2> corners; };
+  FrameSource& src_;
+  double quality_;
+  int min_dist_;
+  sfmx_ctx* ctx_ = nullptr;
+  sfmx_pyramid* pyr_ = nullptr;
+  std::unique_ptr<CornerDetector> det_;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_req_, cv_done_;
+  std::deque<int> queue_;
+  std::unordered_map<int, Slot> slots_;
+  bool stop_ = false;
 };
 
 // KLTTracker (T:323-466) on the GPU
@@ -76,8 +130,14 @@ class GpuTracker {
   const std::vector<Track>& tracks() const { return tracks_; }
   sfmx_pyramid* current() const { return prev_; }  // pyramid of the most recent frame
   const LKConfig& cfg() const { return cfg_; }
-  // shi_tomasi (T:237-302): device score + ordered candidate compaction, host sort + greedy pick
-  std::vector<V2> shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist);
+  // shi_tomasi (T:237-302): device score + certain-outcome fixpoint, host sort + greedy pick on the survivors.
+  // frame_key >= 0 memoises the accepted-corner sequence of that frame: the greedy pick accepts candidates in
+  // a fixed order and max_corners only truncates it, so a later call on the same image with the same
+  // quality / min_dist (the loop-closure verification re-detects corners on old keyframe images, T:1841)
+  // is a prefix of the stored sequence.
+  std::vector<V2> shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist, int frame_key = -1);
+  void forget_corners(int frame_key) { corner_cache_.erase(frame_key); }
+  void set_prefetcher(CornerPrefetcher* p) { prefetch_ = p; }
   // fwd/bwd track of arbitrary points between two pyramids (loop-closure verification, T:1847-1854)
   void track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd, std::vector<std::uint8_t>& keep);
   int levels_total() const { return levels_total_; }
@@ -93,11 +153,10 @@ class GpuTracker {
   std::vector<Track> tracks_;
   int next_id_ = 0;
   StageClock* clk_;
-  std::vector<std::uint32_t> cand_xy_;
-  std::vector<double> cand_s_, all_s_;
-  std::vector<std::int32_t> cand_full_;
-  std::vector<SortKey> keys_;
-  std::vector<int> pos_;
+  CornerDetector det_;
+  CornerPrefetcher* prefetch_ = nullptr;
+  struct CornerMemo { double quality; int min_dist; int cap; bool exhausted; std::vector<V2> corners; };
+  std::unordered_map<int, CornerMemo> corner_cache_;
 };
 
 struct RelPose {
