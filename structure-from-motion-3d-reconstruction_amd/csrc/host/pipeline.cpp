@@ -536,20 +536,25 @@ void MapState::add_obs(int tid, int kf_id, V2 uv) {
 // ------------------------------------------------------------------------------------------ BA
 GpuBundleAdjuster::~GpuBundleAdjuster() { sfmx_ba_destroy(ctx_, prob_); }
 
-void GpuBundleAdjuster::run(const Mat3& K, std::vector<Keyframe>& kfs, MapState& map, const BAConfig& cfg) {
+BaJob GpuBundleAdjuster::gather(const Mat3& K, const std::vector<Keyframe>& kfs, const MapState& map, const BAConfig& cfg) {
+  BaJob job;
+  job.K = K;
+  job.cfg = cfg;
   const int N = (int)kfs.size();
-  if (N < 2) return;
+  if (N < 2) return job;
   const int w0 = std::max(0, N - cfg.window), W = N - w0;
-  if (W < 2) return;
-  const auto t0 = Clock::now();
+  if (W < 2) return job;
   std::unordered_map<int, int> kf2local;
   kf2local.reserve((size_t)W);
   for (int li = 0; li < W; ++li) kf2local.emplace(kfs[(size_t)(w0 + li)].kf_id, li);
   // points with >= 2 window observations, in the map's iteration order (T:871-882)
-  std::vector<double> X, uv;
-  std::vector<std::int32_t> optr{0}, oli;
+  std::vector<double>& X = job.X;
+  std::vector<double>& uv = job.uv;
+  std::vector<std::int32_t>& optr = job.optr;
+  std::vector<std::int32_t>& oli = job.oli;
+  optr.push_back(0);
   int P = 0;
-  for (auto& kv : map.pts) {
+  for (const auto& kv : map.pts) {
     const size_t mark = oli.size();
     for (const auto& ob : kv.second.obs) {
       auto it = kf2local.find(ob.first);
@@ -567,22 +572,35 @@ void GpuBundleAdjuster::run(const Mat3& K, std::vector<Keyframe>& kfs, MapState&
     optr.push_back((std::int32_t)oli.size());
     if (++P >= cfg.max_points) break;
   }
-  if (P == 0) return;
+  if (P == 0) return job;
   if (W > 64) throw SfmxFailure(SFMX_ERR_UNSUPPORTED, "ba.window > 64 is not supported");
-  if (!prob_) check(ctx_, sfmx_ba_create(ctx_, W, P, X.data(), optr.data(), oli.data(), uv.data(), &prob_), "ba_create");
-  else check(ctx_, sfmx_ba_reset(ctx_, prob_, W, P, X.data(), optr.data(), oli.data(), uv.data()), "ba_reset");
-  const int D = 6 * W;
+  job.w0 = w0;
+  job.W = W;
+  job.P = P;
+  job.win.resize((size_t)W);
+  for (int li = 0; li < W; li++) job.win[(size_t)li] = kfs[(size_t)(w0 + li)].pose;
+  job.valid = true;
+  return job;
+}
+
+void GpuBundleAdjuster::solve(BaJob& job) {
+  if (!job.valid) return;
+  const auto t0 = Clock::now();
+  const int W = job.W, P = job.P, D = 6 * W;
+  const Mat3& K = job.K;
+  if (!prob_) check(ctx_, sfmx_ba_create(ctx_, W, P, job.X.data(), job.optr.data(), job.oli.data(), job.uv.data(), &prob_), "ba_create");
+  else check(ctx_, sfmx_ba_reset(ctx_, prob_, W, P, job.X.data(), job.optr.data(), job.oli.data(), job.uv.data()), "ba_reset");
   std::vector<double> poses((size_t)W * 12), dx((size_t)D);
   if (clk_) clk_->ba_calls++;
-  for (int it = 0; it < cfg.iters; ++it) {
+  for (int it = 0; it < job.cfg.iters; ++it) {
     for (int li = 0; li < W; li++) {
       Mat3 R;
       V3 t;
-      inv_wc(kfs[(size_t)(w0 + li)].pose, R, t);
+      inv_wc(job.win[(size_t)li], R, t);
       std::memcpy(&poses[(size_t)12 * li], R.a, 72);
       poses[(size_t)12 * li + 9] = t.x; poses[(size_t)12 * li + 10] = t.y; poses[(size_t)12 * li + 11] = t.z;
     }
-    const int rc = sfmx_ba_step(ctx_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), cfg.huber_delta, cfg.lambda, dx.data());
+    const int rc = sfmx_ba_step(ctx_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), job.cfg.huber_delta, job.cfg.lambda, dx.data());
     if (clk_) { clk_->ba_kernel_us += sfmx_last_kernel_us(ctx_); clk_->ba_iters++; }
     if (rc == SFMX_ERR_SINGULAR) break;  // T:1076-1078: ill-conditioned -> skip the rest of BA
     check(ctx_, rc, "ba_step");
@@ -591,15 +609,76 @@ void GpuBundleAdjuster::run(const Mat3& K, std::vector<Keyframe>& kfs, MapState&
       const V3 v{dx[(size_t)6 * li + 3], dx[(size_t)6 * li + 4], dx[(size_t)6 * li + 5]};
       Mat3 R;
       V3 t;
-      inv_wc(kfs[(size_t)(w0 + li)].pose, R, t);
+      inv_wc(job.win[(size_t)li], R, t);
       const Mat3 R2 = so3_exp(w) * R;
       const V3 t2 = t + v;
       const Mat3 Rcw = transpose(R2);
-      kfs[(size_t)(w0 + li)].pose.R = Rcw;
-      kfs[(size_t)(w0 + li)].pose.t = -(Rcw * t2);
+      job.win[(size_t)li].R = Rcw;
+      job.win[(size_t)li].t = -(Rcw * t2);
     }
   }
   if (clk_) clk_->ba += since(t0);
+}
+
+void GpuBundleAdjuster::apply(const BaJob& job, std::vector<Keyframe>& kfs) {
+  if (!job.valid) return;
+  for (int li = 1; li < job.W; ++li) kfs[(size_t)(job.w0 + li)].pose = job.win[(size_t)li];
+}
+
+// ------------------------------------------------------------------------------------------ async lane
+AsyncLane::AsyncLane(int device) {
+  check(nullptr, sfmx_ctx_create(device, &ctx_), "ctx_create(lane)");
+  th_ = std::thread([this] { run(); });
+}
+AsyncLane::~AsyncLane() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_task_.notify_all();
+  if (th_.joinable()) th_.join();
+  sfmx_ctx_destroy(ctx_);
+}
+void AsyncLane::submit(std::function<void()> task) {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    queue_.push_back(std::move(task));
+  }
+  cv_task_.notify_one();
+}
+void AsyncLane::wait() {
+  std::unique_lock<std::mutex> lk(mu_);
+  cv_idle_.wait(lk, [&] { return queue_.empty() && !busy_; });
+  if (error_) {
+    std::exception_ptr e = error_;
+    error_ = nullptr;
+    std::rethrow_exception(e);
+  }
+}
+void AsyncLane::run() {
+  (void)sfmx_ctx_make_current(ctx_);
+  for (;;) {
+    std::function<void()> task;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_task_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+      if (stop_ && queue_.empty()) return;
+      task = std::move(queue_.front());
+      queue_.pop_front();
+      busy_ = true;
+    }
+    try {
+      task();
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!error_) error_ = std::current_exception();
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      busy_ = false;
+    }
+    cv_idle_.notify_all();
+  }
 }
 
 // T:1131-1197 (assembly on the host, solve through the C ABI)
@@ -690,7 +769,24 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance);
     tracker.set_prefetcher(prefetch.get());
   }
-  GpuBundleAdjuster ba(ctx, &clk);
+  // Lane B: the keyframe->keyframe RANSAC (its edge only feeds the pose graph / CSV) and the local BA of keyframe k
+  // do not feed frame k+1's tracking or frame->frame RANSAC, so they run on a second context while the main
+  // thread goes on; they are joined before the next keyframe is built (triangulation reads the refined poses)
+  // and before any pose-graph use.  SFMX_NO_ASYNC=1 runs everything on the main lane.
+  const bool use_lane = !std::getenv("SFMX_NO_ASYNC");
+  StageClock lane_clk;
+  std::unique_ptr<AsyncLane> lane;
+  if (use_lane) lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
+  sfmx_ctx* bctx = lane ? lane->ctx() : ctx;
+  StageClock* bclk = lane ? &lane_clk : &clk;
+  GpuBundleAdjuster ba(bctx, bclk);
+  struct PendingEdge { int i, j; std::optional<RelPose> rel; };
+  std::deque<PendingEdge> pending_edges;
+  BaJob pending_ba;
+  struct LaneGuard {  // declared after everything the lane's tasks reference: drained first when unwinding
+    AsyncLane* l;
+    ~LaneGuard() { if (l) { try { l->wait(); } catch (...) {} } }
+  } lane_guard{lane.get()};
   sfmx_pyramid* old_pyr = nullptr;  // loop-closure verification image (T:1834)
   struct Guard { sfmx_ctx* c; sfmx_pyramid** p; ~Guard() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard{ctx, &old_pyr};
 
@@ -698,6 +794,15 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   std::vector<Keyframe>& kfs = out.kfs;
   MapState& map = out.map;
   std::vector<PGEdge>& edges = out.edges;
+  // wait for lane B and fold its results in, in submission order (odometry edge of keyframe k, then BA(k))
+  auto join_lane = [&]() {
+    if (lane) lane->wait();
+    for (PendingEdge& pe : pending_edges)
+      if (pe.rel) edges.push_back(PGEdge{pe.i, pe.j, pe.rel->R_ji, pe.rel->t_ji, (int)pe.rel->inliers.size(), false});
+    pending_edges.clear();
+    GpuBundleAdjuster::apply(pending_ba, kfs);
+    pending_ba = BaJob{};
+  };
   std::vector<std::vector<float>> kf_desc;
   Arena* arena = out.arena.get();
   ArenaMap<int, std::vector<std::pair<int, V2>>> track_hist(0, std::hash<int>(), std::equal_to<int>(),
@@ -757,6 +862,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       else make_kf = parallax >= cfg.kf_parallax_px;
     }
     if (make_kf) {
+      join_lane();  // BA(k-1) refined the poses the triangulation below reads; edges stay in keyframe order
       Keyframe kf(arena);
       kf.kf_id = (int)kfs.size();
       kf.frame_idx = fi;
@@ -784,8 +890,13 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         }
         clk.bookkeeping += since(tb0);
         if (ei.size() >= 80) {
-          auto eopt = find_E_ransac_gpu(ctx, K, ei, ej, 2500, 1e-3, 60, &clk);
-          if (eopt) edges.push_back(PGEdge{prev_kf.kf_id, kf.kf_id, eopt->R_ji, eopt->t_ji, (int)eopt->inliers.size(), false});
+          pending_edges.push_back(PendingEdge{prev_kf.kf_id, kf.kf_id, std::nullopt});
+          PendingEdge* slot = &pending_edges.back();  // std::deque: stays valid while later edges are appended
+          auto task = [slot, bctx, bclk, K, ei = std::move(ei), ej = std::move(ej)]() {
+            slot->rel = find_E_ransac_gpu(bctx, K, ei, ej, 2500, 1e-3, 60, bclk);
+          };
+          if (lane) lane->submit(std::move(task));
+          else task();
         }
       }
       if (kfs.size() >= 1) {  // triangulate new points (T:1801-1813)
@@ -826,7 +937,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       kfs.push_back(std::move(kf));
       kf_desc.push_back(new_desc);
       last_kf_frame = fi;
-      ba.run(K, kfs, map, cfg.ba);  // T:1820
+      // T:1820: local BA.  The point/observation gather reads kfs and map now; the device iterations refine a
+      // private copy of the window poses on lane B and are written back at the next join.
+      pending_ba = GpuBundleAdjuster::gather(K, kfs, map, cfg.ba);
+      if (lane) lane->submit([&ba, &pending_ba]() { ba.solve(pending_ba); });
+      else ba.solve(pending_ba);
+      if (!lane) join_lane();
 
       // loop closure (T:1822-1866)
       const int new_kf_id = kfs.back().kf_id;
@@ -856,15 +972,23 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         if (li.size() >= 120) {
           auto lopt = find_E_ransac_gpu(ctx, K, li, lj, 4000, 2e-3, 80, &clk);
           if (lopt && (int)lopt->inliers.size() >= 100) {
+            join_lane();  // the pose graph needs this keyframe's odometry edge and BA result first
             edges.push_back(PGEdge{old_kf.kf_id, new_kf_id, lopt->R_ji, lopt->t_ji, (int)lopt->inliers.size(), true});
             (void)posegraph_optimize_centers(ctx, kfs, edges);
-            ba.run(K, kfs, map, cfg.ba);
+            ba.run(K, kfs, map, cfg.ba);  // lane B is idle here: its context is used from this thread
           }
         }
       }
     }
     if (!make_kf) tracker.forget_corners(fi);  // only keyframe images are ever re-detected (loop closure)
     emit(fi);
+  }
+  join_lane();
+  if (lane) {  // lane B's counters
+    clk.ba += lane_clk.ba; clk.ba_kernel_us += lane_clk.ba_kernel_us; clk.ba_calls += lane_clk.ba_calls; clk.ba_iters += lane_clk.ba_iters;
+    clk.ransac += lane_clk.ransac; clk.ransac_kernel_us += lane_clk.ransac_kernel_us; clk.ransac_calls += lane_clk.ransac_calls;
+    clk.ransac_points += lane_clk.ransac_points; clk.ransac_verified += lane_clk.ransac_verified;
+    clk.r_pre += lane_clk.r_pre; clk.r_gpu += lane_clk.r_gpu; clk.r_verify += lane_clk.r_verify; clk.r_decomp += lane_clk.r_decomp;
   }
   out.log = so.str();
   if (prefetch) {

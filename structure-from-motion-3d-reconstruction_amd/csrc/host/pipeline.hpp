@@ -6,6 +6,8 @@
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
+#include <exception>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -203,17 +205,59 @@ struct PGEdge {
   bool is_loop = false;
 };
 
-// bundle_adjust_window (T:848-1097): S,b build + solve on the device, SO(3) update on the host
+// bundle_adjust_window (T:848-1097) in three steps so that the GPU part can run on another lane:
+//   gather (host, touches kfs/map): window selection + the reference's point collection order (T:853-883);
+//   solve  (device + SO(3) updates on private pose copies): the iteration loop (T:893-1096);
+//   apply  (host): write the refined poses back into kfs[w0+1..] (T:1093-1094).
+struct BaJob {
+  bool valid = false;
+  int w0 = 0, W = 0, P = 0;
+  Mat3 K;
+  BAConfig cfg;
+  std::vector<double> X, uv;
+  std::vector<std::int32_t> optr, oli;
+  std::vector<Pose> win;  // the window's camera->world poses; refined in place by solve()
+};
 class GpuBundleAdjuster {
  public:
   GpuBundleAdjuster(sfmx_ctx* ctx, StageClock* clk) : ctx_(ctx), clk_(clk) {}
   ~GpuBundleAdjuster();
-  void run(const Mat3& K, std::vector<Keyframe>& kfs, MapState& map, const BAConfig& cfg);
+  static BaJob gather(const Mat3& K, const std::vector<Keyframe>& kfs, const MapState& map, const BAConfig& cfg);
+  void solve(BaJob& job);
+  static void apply(const BaJob& job, std::vector<Keyframe>& kfs);
+  void run(const Mat3& K, std::vector<Keyframe>& kfs, MapState& map, const BAConfig& cfg) {
+    BaJob j = gather(K, kfs, map, cfg);
+    solve(j);
+    apply(j, kfs);
+  }
 
  private:
   sfmx_ctx* ctx_;
   StageClock* clk_;
   sfmx_ba_problem* prob_ = nullptr;
+};
+
+// A second execution lane: one worker thread with its OWN sfmx context (own HIP stream and device buffers).
+// Tasks run in submission order; wait() blocks until the lane is idle and rethrows the first task exception.
+class AsyncLane {
+ public:
+  explicit AsyncLane(int device);
+  ~AsyncLane();
+  AsyncLane(const AsyncLane&) = delete;
+  AsyncLane& operator=(const AsyncLane&) = delete;
+  sfmx_ctx* ctx() const { return ctx_; }
+  void submit(std::function<void()> task);
+  void wait();
+
+ private:
+  void run();
+  sfmx_ctx* ctx_ = nullptr;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_task_, cv_idle_;
+  std::deque<std::function<void()>> queue_;
+  bool busy_ = false, stop_ = false;
+  std::exception_ptr error_;
 };
 
 bool posegraph_optimize_centers(sfmx_ctx* ctx, std::vector<Keyframe>& kfs, const std::vector<PGEdge>& edges);

@@ -20,10 +20,12 @@ class ThreadPool {
     return p;
   }
   int size() const { return (int)workers_.size() + 1; }
-  // calls fn(i) for i in [0,n); the calling thread participates.  Not re-entrant.
+  // calls fn(i) for i in [0,n); the calling thread participates.
   void parallel_for(int n, const std::function<void(int)>& fn, int grain = 16) {
     if (n <= 0) return;
-    if (workers_.empty() || n <= grain) {
+    // one parallel region at a time: a second caller (another pipeline lane) simply runs its items serially
+    std::unique_lock<std::mutex> region(region_mu_, std::try_to_lock);
+    if (workers_.empty() || n <= grain || !region.owns_lock()) {
       for (int i = 0; i < n; i++) fn(i);
       return;
     }
@@ -84,7 +86,7 @@ class ThreadPool {
     }
   }
   std::vector<std::thread> workers_;
-  std::mutex m_;
+  std::mutex m_, region_mu_;
   std::condition_variable cv_, done_cv_;
   const std::function<void(int)>* fn_ = nullptr;
   int n_ = 0, grain_ = 16, pending_ = 0;

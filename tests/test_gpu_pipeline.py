@@ -124,3 +124,26 @@ def test_shi_fast_path_equals_full_sort(tmp_path):
             outs.append((p.stdout.replace(out, "X"), out))
         assert outs[0][0] == outs[1][0]
         _same_files(outs[0][1], outs[1][1])
+
+
+def test_async_lanes_do_not_change_results(tmp_path):
+    """Corner prefetch (worker context) and lane B (async kf->kf RANSAC + BA) only reorder WHEN work happens:
+    outputs must be byte-identical to the fully serial schedule (SFMX_NO_PREFETCH / SFMX_NO_ASYNC / SFMX_NO_GRAPH)."""
+    g = np.load(os.path.join(H.GOLDEN, "e2e_loop.npz"))
+    cfgj = json.loads(str(g["config"]))
+    names = [str(s) for s in g["names"]]
+    root = str(tmp_path / "data")
+    synth.write_dataset(root, dict(images=g["images"], K=g["K"], R=g["R"], t=g["t"], names=names, lat=g["lat"], lon=g["lon"]))
+    with open(os.path.join(root, "cfg.json"), "w") as f:
+        json.dump(cfgj, f)
+    outs = []
+    for extra in ({}, {"SFMX_NO_PREFETCH": "1", "SFMX_NO_ASYNC": "1", "SFMX_NO_GRAPH": "1"}, {"SFMX_NO_ASYNC": "1"}, {"SFMX_NO_PREFETCH": "1"}):
+        out = os.path.join(root, f"out{len(outs)}")
+        p = subprocess.run([pipe.CLI_PATH, root, out, "--config", os.path.join(root, "cfg.json")], capture_output=True, text=True,
+                           cwd=root, env={**os.environ, **extra})
+        assert p.returncode == 0, p.stderr
+        outs.append((p.stdout.replace(out, "X"), out))
+    for k in range(1, len(outs)):
+        assert outs[0][0] == outs[k][0]
+        _same_files(outs[0][1], outs[k][1])
+    check_e2e_against_reference(g, outs[0][0].replace("X", outs[0][1]), outs[0][1])
