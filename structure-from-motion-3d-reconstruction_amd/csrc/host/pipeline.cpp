@@ -220,28 +220,42 @@ std::vector<V2> CornerDetector::detect(sfmx_pyramid* pyr, int max_corners, doubl
 }
 
 // ------------------------------------------------------------------------------------------ prefetcher
-CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist)
+CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist, int workers)
     : src_(src), quality_(quality), min_dist_(min_dist) {
-  check(nullptr, sfmx_ctx_create(device, &ctx_), "ctx_create(prefetch)");
   try {
-    check(ctx_, sfmx_pyramid_create(ctx_, src.width(), src.height(), 1, &pyr_), "pyramid_create(prefetch)");
+    for (int i = 0; i < std::max(1, workers); ++i) {
+      auto w = std::make_unique<Worker>();
+      check(nullptr, sfmx_ctx_create(device, &w->ctx), "ctx_create(prefetch)");
+      workers_.push_back(std::move(w));
+      Worker& ww = *workers_.back();
+      check(ww.ctx, sfmx_pyramid_create(ww.ctx, src.width(), src.height(), 1, &ww.pyr), "pyramid_create(prefetch)");
+      ww.det = std::make_unique<CornerDetector>(ww.ctx, &ww.clock);
+    }
+    for (auto& w : workers_) w->th = std::thread([this, p = w.get()] { run(*p); });
   } catch (...) {
-    sfmx_ctx_destroy(ctx_);
+    shutdown();
     throw;
   }
-  det_ = std::make_unique<CornerDetector>(ctx_, &clock);
-  th_ = std::thread([this] { run(); });
 }
-CornerPrefetcher::~CornerPrefetcher() {
+void CornerPrefetcher::shutdown() {
   {
     std::lock_guard<std::mutex> lk(mu_);
     stop_ = true;
   }
   cv_req_.notify_all();
-  if (th_.joinable()) th_.join();
-  det_.reset();
-  sfmx_pyramid_destroy(ctx_, pyr_);
-  sfmx_ctx_destroy(ctx_);
+  for (auto& w : workers_) {
+    if (w->th.joinable()) w->th.join();
+    w->det.reset();
+    if (w->pyr) sfmx_pyramid_destroy(w->ctx, w->pyr);
+    if (w->ctx) sfmx_ctx_destroy(w->ctx);
+  }
+  workers_.clear();
+}
+CornerPrefetcher::~CornerPrefetcher() { shutdown(); }
+std::uint64_t CornerPrefetcher::replays() {
+  std::uint64_t n = 0;
+  for (auto& w : workers_) n += w->clock.shi_fallbacks;
+  return n;
 }
 void CornerPrefetcher::request(int frame) {
   {
@@ -269,8 +283,8 @@ bool CornerPrefetcher::take(int frame, std::vector<V2>& corners) {
   slots_.erase(frame);
   return ok;
 }
-void CornerPrefetcher::run() {
-  (void)sfmx_ctx_make_current(ctx_);  // HIP's current device is per thread
+void CornerPrefetcher::run(Worker& w) {
+  (void)sfmx_ctx_make_current(w.ctx);  // HIP's current device is per thread
   for (;;) {
     int frame;
     {
@@ -283,8 +297,8 @@ void CornerPrefetcher::run() {
     std::vector<V2> seq;
     bool failed = false;
     try {
-      src_.load(ctx_, frame, pyr_);
-      seq = det_->detect(pyr_, 0x3fffffff, quality_, min_dist_);  // uncapped: every later request is a prefix
+      src_.load(w.ctx, frame, w.pyr);
+      seq = w.det->detect(w.pyr, 0x3fffffff, quality_, min_dist_);  // uncapped: every later request is a prefix
     } catch (...) {
       failed = true;  // the main thread recomputes synchronously and reports the error where the reference would
     }
@@ -310,24 +324,28 @@ void GpuTracker::reset(FrameSource& src, int fi) {
   for (const V2& p : shi_tomasi(prev_, cfg_.max_tracks, cfg_.quality, cfg_.min_distance, fi)) tracks_.push_back({next_id_++, p});
 }
 
-void GpuTracker::track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
-                             std::vector<std::uint8_t>& keep) {
+void klt_pairs(sfmx_ctx* ctx, const LKConfig& cfg, const sfmx_pyramid* a, const sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
+               std::vector<std::uint8_t>& keep, StageClock* clk) {
   const int n = (int)p0.size();
   fwd.resize((size_t)n);
   keep.resize((size_t)n);
   if (n == 0) return;
   static_assert(sizeof(V2) == 16, "V2 must be two packed doubles");
-  sfmx_klt_cfg kc{cfg_.pyr_levels, cfg_.win_radius, cfg_.iters, cfg_.fb_thresh};
+  sfmx_klt_cfg kc{cfg.pyr_levels, cfg.win_radius, cfg.iters, cfg.fb_thresh};
   std::uint64_t steps = 0;
   const auto t0 = Clock::now();
-  check(ctx_, sfmx_klt_track(ctx_, a, b, &p0[0].x, n, &kc, &fwd[0].x, nullptr, keep.data(), &steps), "klt_track");
-  if (clk_) {
-    clk_->klt += since(t0);
-    clk_->klt_kernel_us += sfmx_last_kernel_us(ctx_);
-    clk_->lk_steps += steps;
-    clk_->tracks_in += (std::uint64_t)n;
-    clk_->klt_calls++;
+  check(ctx, sfmx_klt_track(ctx, a, b, &p0[0].x, n, &kc, &fwd[0].x, nullptr, keep.data(), &steps), "klt_track");
+  if (clk) {
+    clk->klt += since(t0);
+    clk->klt_kernel_us += sfmx_last_kernel_us(ctx);
+    clk->lk_steps += steps;
+    clk->tracks_in += (std::uint64_t)n;
+    clk->klt_calls++;
   }
+}
+void GpuTracker::track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
+                             std::vector<std::uint8_t>& keep) {
+  klt_pairs(ctx_, cfg_, a, b, p0, fwd, keep, clk_);
 }
 
 StepOut GpuTracker::step(FrameSource& src, int fi) {
@@ -764,29 +782,46 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   const int dlevel = desc_level(w, h);
   if (dlevel + 1 > 8 || cfg.klt.pyr_levels > 8) throw SfmxFailure(SFMX_ERR_UNSUPPORTED, "image too large for an 8-level pyramid");
   GpuTracker tracker(ctx, cfg.klt, w, h, dlevel + 1, &clk);
+  // one worker keeps frame f+1 in flight; more (SFMX_PREFETCH_WORKERS) remove the residual wait but the extra
+  // contexts slow the other lanes down by more than that on one GPU (measured: 1 -> 552, 2 -> 498, 3 -> 510 kf/s)
+  int prefetch_workers = 1;
+  if (const char* e = std::getenv("SFMX_PREFETCH_WORKERS")) prefetch_workers = std::min(4, std::max(1, std::atoi(e)));
   std::unique_ptr<CornerPrefetcher> prefetch;
   if (!std::getenv("SFMX_NO_PREFETCH") && std::min(cfg.frames, src.count()) > 1 && cfg.klt.min_distance >= 1 && cfg.klt.min_distance <= 16) {
-    prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance);
+    prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance, prefetch_workers);
     tracker.set_prefetcher(prefetch.get());
   }
   // Lane B: the keyframe->keyframe RANSAC (its edge only feeds the pose graph / CSV) and the local BA of keyframe k
   // do not feed frame k+1's tracking or frame->frame RANSAC, so they run on a second context while the main
   // thread goes on; they are joined before the next keyframe is built (triangulation reads the refined poses)
   // and before any pose-graph use.  SFMX_NO_ASYNC=1 runs everything on the main lane.
+  // Lane C takes the loop-closure verification of keyframe k (KLT old-keyframe -> new-keyframe + RANSAC, T:1834-1858):
+  // its verdict is only consumed -- pose graph + second BA, T:1859-1863 -- before the next keyframe is built.
   const bool use_lane = !std::getenv("SFMX_NO_ASYNC");
-  StageClock lane_clk;
-  std::unique_ptr<AsyncLane> lane;
-  if (use_lane) lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
+  StageClock lane_clk, lane_c_clk;
+  std::unique_ptr<AsyncLane> lane, lane_c;
+  if (use_lane) {
+    lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
+    lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
+  }
   sfmx_ctx* bctx = lane ? lane->ctx() : ctx;
   StageClock* bclk = lane ? &lane_clk : &clk;
+  sfmx_ctx* cctx = lane_c ? lane_c->ctx() : ctx;
+  StageClock* cclk = lane_c ? &lane_c_clk : &clk;
   GpuBundleAdjuster ba(bctx, bclk);
+  sfmx_pyramid* old_pyr_c = nullptr;  // lane C's copy of the old keyframe image
+  struct PyrGuardC { sfmx_ctx* c; sfmx_pyramid** p; ~PyrGuardC() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard_c{cctx, &old_pyr_c};
   struct PendingEdge { int i, j; std::optional<RelPose> rel; };
   std::deque<PendingEdge> pending_edges;
   BaJob pending_ba;
-  struct LaneGuard {  // declared after everything the lane's tasks reference: drained first when unwinding
-    AsyncLane* l;
-    ~LaneGuard() { if (l) { try { l->wait(); } catch (...) {} } }
-  } lane_guard{lane.get()};
+  struct PendingLoop { bool active = false; int frame = -1, old_kf = -1, new_kf = -1; std::optional<RelPose> rel; } pending_loop;
+  struct LaneGuard {  // declared after everything the lanes' tasks reference: drained first when unwinding
+    AsyncLane *l, *m;
+    ~LaneGuard() {
+      if (l) { try { l->wait(); } catch (...) {} }
+      if (m) { try { m->wait(); } catch (...) {} }
+    }
+  } lane_guard{lane.get(), lane_c.get()};
   sfmx_pyramid* old_pyr = nullptr;  // loop-closure verification image (T:1834)
   struct Guard { sfmx_ctx* c; sfmx_pyramid** p; ~Guard() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard{ctx, &old_pyr};
 
@@ -797,16 +832,27 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   // wait for lane B and fold its results in, in submission order (odometry edge of keyframe k, then BA(k))
   auto join_lane = [&]() {
     if (lane) lane->wait();
+    if (lane_c) lane_c->wait();
     for (PendingEdge& pe : pending_edges)
       if (pe.rel) edges.push_back(PGEdge{pe.i, pe.j, pe.rel->R_ji, pe.rel->t_ji, (int)pe.rel->inliers.size(), false});
     pending_edges.clear();
     GpuBundleAdjuster::apply(pending_ba, kfs);
     pending_ba = BaJob{};
+    if (pending_loop.active) {  // verdict of the loop-closure verification of the last keyframe (T:1858-1864)
+      const PendingLoop pl = pending_loop;
+      pending_loop = PendingLoop{};
+      if (pl.rel && (int)pl.rel->inliers.size() >= 100) {
+        edges.push_back(PGEdge{pl.old_kf, pl.new_kf, pl.rel->R_ji, pl.rel->t_ji, (int)pl.rel->inliers.size(), true});
+        (void)posegraph_optimize_centers(ctx, kfs, edges);
+        ba.run(K, kfs, map, cfg.ba);  // the lanes are idle here: lane B's context is used from this thread
+      }
+    }
   };
   std::vector<std::vector<float>> kf_desc;
   Arena* arena = out.arena.get();
-  ArenaMap<int, std::vector<std::pair<int, V2>>> track_hist(0, std::hash<int>(), std::equal_to<int>(),
-                                                              ArenaAlloc<std::pair<const int, std::vector<std::pair<int, V2>>>>(arena));
+  // mapped: the track already has a map point (== map.has(tid), kept in the node the walk below touches anyway)
+  struct TrackHist { std::vector<std::pair<int, V2>> obs; bool mapped = false; };
+  ArenaMap<int, TrackHist> track_hist(0, std::hash<int>(), std::equal_to<int>(), ArenaAlloc<std::pair<const int, TrackHist>>(arena));
   int last_kf_frame = -999999;
   const int frames = cfg.frames;
   std::ostringstream so;
@@ -817,10 +863,13 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     if (echo) echo(line.str());
   };
 
+  clk.setup = since(t_all);
   for (int fi = 0; fi < std::min(frames, src.count()); ++fi) {
+    if (pending_loop.active && fi >= pending_loop.frame + 2) join_lane();  // its 'current' pyramid is about to be reused
     if (prefetch) {
       prefetch->discard_older_than(fi);  // results nobody asked for (no replenish on that frame)
-      if (fi + 1 < std::min(frames, src.count())) prefetch->request(fi + 1);  // overlaps with this frame's work
+      for (int a = 1; a <= prefetch_workers; ++a)  // one frame in flight per worker, overlapping this frame's work
+        if (fi + a < std::min(frames, src.count())) prefetch->request(fi + a);
     }
     StepOut step = tracker.step(src, fi);
     if (step.prev_pts.empty()) {  // first keyframe (T:1715-1733)
@@ -832,7 +881,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       kf_desc.push_back(global_desc_32(ctx, tracker.current(), dlevel));
       for (const Track& tr : tracker.tracks()) {
         kf.obs.emplace(tr.id, tr.p);
-        track_hist[tr.id].push_back({kf.kf_id, tr.p});
+        track_hist[tr.id].obs.push_back({kf.kf_id, tr.p});
       }
       kfs.push_back(std::move(kf));
       last_kf_frame = fi;
@@ -874,8 +923,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       const auto tb0 = Clock::now();
       for (const Track& tr : tracker.tracks()) {
         kf.obs.emplace(tr.id, tr.p);
-        track_hist[tr.id].push_back({kf.kf_id, tr.p});
-        if (map.has(tr.id)) map.add_obs(tr.id, kf.kf_id, tr.p);
+        TrackHist& th = track_hist[tr.id];
+        th.obs.push_back({kf.kf_id, tr.p});
+        if (th.mapped) map.add_obs(tr.id, kf.kf_id, tr.p);
       }
       if (!kfs.empty()) {  // sequential pose-graph edge (T:1782-1798)
         const Keyframe& prev_kf = kfs.back();
@@ -892,10 +942,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         if (ei.size() >= 80) {
           pending_edges.push_back(PendingEdge{prev_kf.kf_id, kf.kf_id, std::nullopt});
           PendingEdge* slot = &pending_edges.back();  // std::deque: stays valid while later edges are appended
-          auto task = [slot, bctx, bclk, K, ei = std::move(ei), ej = std::move(ej)]() {
-            slot->rel = find_E_ransac_gpu(bctx, K, ei, ej, 2500, 1e-3, 60, bclk);
+          auto task = [slot, cctx, cclk, K, ei = std::move(ei), ej = std::move(ej)]() {
+            slot->rel = find_E_ransac_gpu(cctx, K, ei, ej, 2500, 1e-3, 60, cclk);
           };
-          if (lane) lane->submit(std::move(task));
+          if (lane_c) lane_c->submit(std::move(task));
           else task();
         }
       }
@@ -903,12 +953,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         const auto th0 = Clock::now();
         // The DLT solves (libm Jacobi) are independent: gather the jobs in the reference's iteration
         // order, solve them on the host pool, then insert into the map sequentially in that same order.
-        struct TriJob { int tid; const std::vector<std::pair<int, V2>>* hist; const Pose* p0; const Pose* pl; V3 X; bool ok; };
+        struct TriJob { int tid; TrackHist* th; const std::vector<std::pair<int, V2>>* hist; const Pose* p0; const Pose* pl; V3 X; bool ok; };
         std::vector<TriJob> jobs;
         for (auto& kv : track_hist) {
           const int tid = kv.first;
-          auto& hist = kv.second;
-          if (map.has(tid) || hist.size() < 2) continue;
+          auto& hist = kv.second.obs;
+          if (kv.second.mapped || hist.size() < 2) continue;
           const int id0 = hist.front().first, idl = hist.back().first;
           if (id0 == idl) continue;
           // Quirk Q12: the reference indexes kfs[idl] at T:1809 before the keyframe under
@@ -916,7 +966,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           // new keyframe — undefined behaviour whose result is heap garbage.  The defined reading is
           // used here: the new keyframe's own pose.
           const Pose* pl = (idl < (int)kfs.size()) ? &kfs[(size_t)idl].pose : &kf.pose;
-          jobs.push_back(TriJob{tid, &hist, &kfs[(size_t)id0].pose, pl, V3{}, true});
+          jobs.push_back(TriJob{tid, &kv.second, &hist, &kfs[(size_t)id0].pose, pl, V3{}, true});
         }
         clk.tri_iter += since(th0);
         const auto ts0 = Clock::now();
@@ -929,6 +979,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         for (const TriJob& j : jobs) {
           if (!j.ok) throw std::runtime_error("Singular K");
           map.add(j.tid, j.X);
+          j.th->mapped = true;
           for (const auto& ob : *j.hist) map.add_obs(j.tid, ob.first, ob.second);
         }
         clk.tri_insert += since(ti0);
@@ -954,37 +1005,48 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       }
       if (best_id >= 0 && best_score > 0.94f) {
         const Keyframe& old_kf = kfs[(size_t)best_id];
-        if (!old_pyr) check(ctx, sfmx_pyramid_create(ctx, w, h, tracker.levels_total(), &old_pyr), "pyramid_create");
-        src.load(ctx, old_kf.frame_idx, old_pyr);
         LKConfig lc = cfg.klt;
         lc.max_tracks = 1200;
         lc.min_tracks = 600;
-        const auto pts0 = tracker.shi_tomasi(old_pyr, lc.max_tracks, lc.quality, lc.min_distance, old_kf.frame_idx);
-        std::vector<V2> fwd;
-        std::vector<std::uint8_t> keep;
-        tracker.track_pairs(old_pyr, tracker.current(), pts0, fwd, keep);
-        std::vector<V2> li, lj;
-        for (size_t i = 0; i < pts0.size(); i++) {
-          if (!keep[i]) continue;
-          li.push_back(pts0[i]);
-          lj.push_back(fwd[i]);
+        // corners of the old keyframe image: memoised when that frame was current (same image, quality, min_dist)
+        if (!old_pyr && !tracker.has_corners(old_kf.frame_idx, lc.quality, lc.min_distance, lc.max_tracks)) {
+          check(ctx, sfmx_pyramid_create(ctx, w, h, tracker.levels_total(), &old_pyr), "pyramid_create");
         }
-        if (li.size() >= 120) {
-          auto lopt = find_E_ransac_gpu(ctx, K, li, lj, 4000, 2e-3, 80, &clk);
-          if (lopt && (int)lopt->inliers.size() >= 100) {
-            join_lane();  // the pose graph needs this keyframe's odometry edge and BA result first
-            edges.push_back(PGEdge{old_kf.kf_id, new_kf_id, lopt->R_ji, lopt->t_ji, (int)lopt->inliers.size(), true});
-            (void)posegraph_optimize_centers(ctx, kfs, edges);
-            ba.run(K, kfs, map, cfg.ba);  // lane B is idle here: its context is used from this thread
+        if (!tracker.has_corners(old_kf.frame_idx, lc.quality, lc.min_distance, lc.max_tracks)) src.load(ctx, old_kf.frame_idx, old_pyr);
+        auto pts0 = tracker.shi_tomasi(old_pyr, lc.max_tracks, lc.quality, lc.min_distance, old_kf.frame_idx);
+        pending_loop = PendingLoop{true, fi, old_kf.kf_id, new_kf_id, std::nullopt};
+        const int old_frame = old_kf.frame_idx;
+        const sfmx_pyramid* cur_pyr = tracker.current();  // stays intact until the frame after next is loaded
+        auto verify = [&, lc, old_frame, cur_pyr, pts0 = std::move(pts0)]() {
+          if (!old_pyr_c) check(cctx, sfmx_pyramid_create(cctx, w, h, tracker.levels_total(), &old_pyr_c), "pyramid_create");
+          src.load(cctx, old_frame, old_pyr_c);
+          std::vector<V2> fwd;
+          std::vector<std::uint8_t> keep;
+          klt_pairs(cctx, lc, old_pyr_c, cur_pyr, pts0, fwd, keep, cclk);
+          std::vector<V2> li, lj;
+          for (size_t i = 0; i < pts0.size(); i++) {
+            if (!keep[i]) continue;
+            li.push_back(pts0[i]);
+            lj.push_back(fwd[i]);
           }
-        }
+          if (li.size() >= 120) pending_loop.rel = find_E_ransac_gpu(cctx, K, li, lj, 4000, 2e-3, 80, cclk);
+        };
+        if (lane_c) lane_c->submit(std::move(verify));
+        else { verify(); join_lane(); }
       }
     }
     if (!make_kf) tracker.forget_corners(fi);  // only keyframe images are ever re-detected (loop closure)
     emit(fi);
   }
   join_lane();
-  if (lane) {  // lane B's counters
+  if (lane_c) {
+    lane_clk.ransac += lane_c_clk.ransac; lane_clk.ransac_kernel_us += lane_c_clk.ransac_kernel_us; lane_clk.ransac_calls += lane_c_clk.ransac_calls;
+    lane_clk.ransac_points += lane_c_clk.ransac_points; lane_clk.ransac_verified += lane_c_clk.ransac_verified;
+    lane_clk.r_pre += lane_c_clk.r_pre; lane_clk.r_gpu += lane_c_clk.r_gpu; lane_clk.r_verify += lane_c_clk.r_verify; lane_clk.r_decomp += lane_c_clk.r_decomp;
+    clk.klt += lane_c_clk.klt; clk.klt_kernel_us += lane_c_clk.klt_kernel_us; clk.lk_steps += lane_c_clk.lk_steps;
+    clk.tracks_in += lane_c_clk.tracks_in; clk.klt_calls += lane_c_clk.klt_calls;
+  }
+  if (lane) {  // lane B's (and, merged above, lane C's) counters
     clk.ba += lane_clk.ba; clk.ba_kernel_us += lane_clk.ba_kernel_us; clk.ba_calls += lane_clk.ba_calls; clk.ba_iters += lane_clk.ba_iters;
     clk.ransac += lane_clk.ransac; clk.ransac_kernel_us += lane_clk.ransac_kernel_us; clk.ransac_calls += lane_clk.ransac_calls;
     clk.ransac_points += lane_clk.ransac_points; clk.ransac_verified += lane_clk.ransac_verified;
@@ -993,7 +1055,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   out.log = so.str();
   if (prefetch) {
     tracker.set_prefetcher(nullptr);
-    clk.shi_fallbacks += prefetch->clock.shi_fallbacks;  // the worker's tie-order replays count too
+    clk.shi_fallbacks += prefetch->replays();  // the worker's tie-order replays count too
     prefetch.reset();
   }
   clk.total = since(t_all);
@@ -1060,7 +1122,7 @@ struct sfmx_pipeline_stats {
   double sec_total, sec_klt, sec_shi, sec_ransac, sec_ba, sec_upload, sec_host, sec_shi_gpu, sec_shi_replay, sec_desc, sec_bookkeeping, sec_r_pre, sec_r_gpu, sec_r_verify, sec_r_decomp, sec_tri_iter, sec_tri_solve, sec_tri_insert;
   double us_klt_kernel, us_ransac_kernel, us_ba_kernel, us_shi_kernel;
   unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks, shi_calls, shi_memo_hits, shi_prefetched;
-  double sec_shi_wait;
+  double sec_shi_wait, sec_setup, sec_wall;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -1071,6 +1133,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
                       double* centres_out, int centres_cap) {
   using namespace sfmx_host;
   if (!ctx || !cfg || !K9 || (!images_host && !images_dev) || n_images <= 0) return SFMX_ERR_INVALID;
+  const auto t_wall = Clock::now();
   try {
     MemoryFrames src;
     src.host = images_host;
@@ -1095,7 +1158,8 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     pc.ba.window = cfg->ba_window; pc.ba.iters = cfg->ba_iters; pc.ba.max_points = cfg->ba_max_points;
     pc.ba.huber_delta = cfg->ba_huber; pc.ba.lambda = cfg->ba_lambda;
     PipelineResult res;
-    run_pipeline(ctx, src, meta, K, pc, res);
+    run_pipeline(ctx, src, meta, K, pc, res);  // returns after its lanes / prefetch contexts are torn down
+    const double wall = since(t_wall);
     if (out_dir) write_outputs(out_dir, pc, meta, res);
     if (log && log_cap > 0) std::snprintf(log, (size_t)log_cap, "%s", res.log.c_str());
     if (stats) {
@@ -1103,7 +1167,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
       *stats = sfmx_pipeline_stats{(int)res.kfs.size(), (int)res.map.pts.size(), (int)res.edges.size(), std::min(pc.frames, n_images),
                                    c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host, c.shi_gpu, c.shi_replay, c.desc, c.bookkeeping, c.r_pre, c.r_gpu, c.r_verify, c.r_decomp, c.tri_iter, c.tri_solve, c.tri_insert,
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
-                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait};
+                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait, c.setup, wall};
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {

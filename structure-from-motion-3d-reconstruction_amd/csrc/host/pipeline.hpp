@@ -70,7 +70,7 @@ struct StageClock {
   double klt_kernel_us = 0, ransac_kernel_us = 0, ba_kernel_us = 0, shi_kernel_us = 0;
   std::uint64_t lk_steps = 0, tracks_in = 0, ransac_calls = 0, ransac_points = 0, ba_calls = 0, ba_iters = 0, klt_calls = 0;
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
-  double shi_wait = 0;
+  double shi_wait = 0, setup = 0;
 };
 
 // shi_tomasi (T:237-302) on one context: device score + certain-outcome fixpoint (sfmx_shi_tomasi_candidates_pruned),
@@ -94,7 +94,7 @@ class CornerDetector {
 // The result is the uncapped accepted-corner sequence; GpuTracker::shi_tomasi takes prefixes of it.
 class CornerPrefetcher {
  public:
-  CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist);
+  CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist, int workers);
   ~CornerPrefetcher();
   CornerPrefetcher(const CornerPrefetcher&) = delete;
   CornerPrefetcher& operator=(const CornerPrefetcher&) = delete;
@@ -102,18 +102,24 @@ class CornerPrefetcher {
   bool take(int frame, std::vector<V2>& corners);   // waits for a requested frame; false if never requested / failed
   void discard_older_than(int frame);               // drop finished results of frames < frame that nobody took
   bool matches(double quality, int min_dist) const { return quality == quality_ && min_dist == min_dist_; }
-  StageClock clock;                                 // the worker's own counters (read after the run)
+  std::uint64_t replays();                          // tie-order replays over all workers (call after the run)
 
  private:
-  void run();
+  // one worker = one thread + one context + one detector; frames are handed out from a shared queue
+  struct Worker {
+    sfmx_ctx* ctx = nullptr;
+    sfmx_pyramid* pyr = nullptr;
+    std::unique_ptr<CornerDetector> det;
+    StageClock clock;
+    std::thread th;
+  };
+  void run(Worker& w);
+  void shutdown();
   struct Slot { bool done = false, failed = false; std::vector<V2> corners; };
   FrameSource& src_;
   double quality_;
   int min_dist_;
-  sfmx_ctx* ctx_ = nullptr;
-  sfmx_pyramid* pyr_ = nullptr;
-  std::unique_ptr<CornerDetector> det_;
-  std::thread th_;
+  std::vector<std::unique_ptr<Worker>> workers_;
   std::mutex mu_;
   std::condition_variable cv_req_, cv_done_;
   std::deque<int> queue_;
@@ -139,6 +145,11 @@ class GpuTracker {
   // is a prefix of the stored sequence.
   std::vector<V2> shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist, int frame_key = -1);
   void forget_corners(int frame_key) { corner_cache_.erase(frame_key); }
+  bool has_corners(int frame_key, double quality, int min_dist, int max_corners) const {
+    auto it = corner_cache_.find(frame_key);
+    return it != corner_cache_.end() && it->second.quality == quality && it->second.min_dist == min_dist && max_corners >= 1 &&
+           (it->second.exhausted || max_corners <= it->second.cap);
+  }
   void set_prefetcher(CornerPrefetcher* p) { prefetch_ = p; }
   // fwd/bwd track of arbitrary points between two pyramids (loop-closure verification, T:1847-1854)
   void track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd, std::vector<std::uint8_t>& keep);
@@ -160,6 +171,10 @@ class GpuTracker {
   struct CornerMemo { double quality; int min_dist; int cap; bool exhausted; std::vector<V2> corners; };
   std::unordered_map<int, CornerMemo> corner_cache_;
 };
+
+// fwd/bwd track of arbitrary points between two pyramids on any context of the same device (loop-closure verification)
+void klt_pairs(sfmx_ctx* ctx, const LKConfig& cfg, const sfmx_pyramid* a, const sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
+               std::vector<std::uint8_t>& keep, StageClock* clk);
 
 struct RelPose {
   Mat3 R_ji;

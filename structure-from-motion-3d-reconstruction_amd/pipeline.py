@@ -33,7 +33,8 @@ class PipelineStats(ctypes.Structure):
                 ("lk_steps", c_ulonglong), ("tracks_in", c_ulonglong), ("klt_calls", c_ulonglong),
                 ("ransac_calls", c_ulonglong), ("ransac_points", c_ulonglong), ("ba_calls", c_ulonglong),
                 ("ba_iters", c_ulonglong), ("ransac_verified", c_ulonglong), ("shi_fallbacks", c_ulonglong),
-                ("shi_calls", c_ulonglong), ("shi_memo_hits", c_ulonglong), ("shi_prefetched", c_ulonglong), ("sec_shi_wait", c_double)]
+                ("shi_calls", c_ulonglong), ("shi_memo_hits", c_ulonglong), ("shi_prefetched", c_ulonglong), ("sec_shi_wait", c_double),
+                ("sec_setup", c_double), ("sec_wall", c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
