@@ -48,6 +48,7 @@ void* sfmx_stream(sfmx_ctx* ctx);
 /* microseconds of GPU time of the most recent hot kernel launched by the last API call, measured
  * with HIP events on the context stream (0 when timing is disabled, see sfmx_set_timing). */
 int sfmx_set_timing(sfmx_ctx* ctx, int enabled);
+int sfmx_get_timing(const sfmx_ctx* ctx); /* 1 if enabled (so that helper contexts can inherit the setting) */
 double sfmx_last_kernel_us(const sfmx_ctx* ctx);
 
 /* ---- image pyramid: replaces sfm::GrayImage + build_pyr/downsample2 (T:200-232) ------------ */

@@ -67,6 +67,7 @@ int sfmx_set_timing(sfmx_ctx* c, int enabled) {
   c->timing = enabled != 0;
   return SFMX_OK;
 }
+int sfmx_get_timing(const sfmx_ctx* c) { return (c && c->timing) ? 1 : 0; }
 double sfmx_last_kernel_us(const sfmx_ctx* c) { return c ? c->last_us : 0.0; }
 
 }  // extern "C"

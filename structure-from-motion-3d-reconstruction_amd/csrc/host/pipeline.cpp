@@ -220,7 +220,7 @@ std::vector<V2> CornerDetector::detect(sfmx_pyramid* pyr, int max_corners, doubl
 }
 
 // ------------------------------------------------------------------------------------------ prefetcher
-CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist, int workers)
+CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist, int workers, bool timing)
     : src_(src), quality_(quality), min_dist_(min_dist) {
   try {
     for (int i = 0; i < std::max(1, workers); ++i) {
@@ -229,6 +229,7 @@ CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality,
       workers_.push_back(std::move(w));
       Worker& ww = *workers_.back();
       check(ww.ctx, sfmx_pyramid_create(ww.ctx, src.width(), src.height(), 1, &ww.pyr), "pyramid_create(prefetch)");
+      if (timing) (void)sfmx_set_timing(ww.ctx, 1);
       ww.det = std::make_unique<CornerDetector>(ww.ctx, &ww.clock);
     }
     for (auto& w : workers_) w->th = std::thread([this, p = w.get()] { run(*p); });
@@ -252,6 +253,15 @@ void CornerPrefetcher::shutdown() {
   workers_.clear();
 }
 CornerPrefetcher::~CornerPrefetcher() { shutdown(); }
+void CornerPrefetcher::busy(double& total, double& gpu, double& replay) {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (auto& w : workers_) { total += w->busy; gpu += w->clock.shi_gpu; replay += w->clock.shi_replay; }
+}
+double CornerPrefetcher::kernel_us() {
+  double us = 0;
+  for (auto& w : workers_) us += w->clock.shi_kernel_us;
+  return us;
+}
 std::uint64_t CornerPrefetcher::replays() {
   std::uint64_t n = 0;
   for (auto& w : workers_) n += w->clock.shi_fallbacks;
@@ -296,6 +306,7 @@ void CornerPrefetcher::run(Worker& w) {
     }
     std::vector<V2> seq;
     bool failed = false;
+    const auto tb = Clock::now();
     try {
       src_.load(w.ctx, frame, w.pyr);
       seq = w.det->detect(w.pyr, 0x3fffffff, quality_, min_dist_);  // uncapped: every later request is a prefix
@@ -304,6 +315,7 @@ void CornerPrefetcher::run(Worker& w) {
     }
     {
       std::lock_guard<std::mutex> lk(mu_);
+      w.busy += since(tb);
       auto it = slots_.find(frame);
       if (it != slots_.end()) {
         it->second.corners = std::move(seq);
@@ -685,6 +697,7 @@ void AsyncLane::run() {
       queue_.pop_front();
       busy_ = true;
     }
+    const auto tb = Clock::now();
     try {
       task();
     } catch (...) {
@@ -693,6 +706,7 @@ void AsyncLane::run() {
     }
     {
       std::lock_guard<std::mutex> lk(mu_);
+      busy_seconds_ += since(tb);
       busy_ = false;
     }
     cv_idle_.notify_all();
@@ -788,7 +802,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   if (const char* e = std::getenv("SFMX_PREFETCH_WORKERS")) prefetch_workers = std::min(4, std::max(1, std::atoi(e)));
   std::unique_ptr<CornerPrefetcher> prefetch;
   if (!std::getenv("SFMX_NO_PREFETCH") && std::min(cfg.frames, src.count()) > 1 && cfg.klt.min_distance >= 1 && cfg.klt.min_distance <= 16) {
-    prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance, prefetch_workers);
+    prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance, prefetch_workers, sfmx_get_timing(ctx) != 0);
     tracker.set_prefetcher(prefetch.get());
   }
   // Lane B: the keyframe->keyframe RANSAC (its edge only feeds the pose graph / CSV) and the local BA of keyframe k
@@ -803,6 +817,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   if (use_lane) {
     lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
     lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
+  }
+  if (sfmx_get_timing(ctx)) {  // per-kernel event timing is inherited by the helper contexts
+    if (lane) (void)sfmx_set_timing(lane->ctx(), 1);
+    if (lane_c) (void)sfmx_set_timing(lane_c->ctx(), 1);
   }
   sfmx_ctx* bctx = lane ? lane->ctx() : ctx;
   StageClock* bclk = lane ? &lane_clk : &clk;
@@ -831,8 +849,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   std::vector<PGEdge>& edges = out.edges;
   // wait for lane B and fold its results in, in submission order (odometry edge of keyframe k, then BA(k))
   auto join_lane = [&]() {
+    const auto tj = Clock::now();
     if (lane) lane->wait();
     if (lane_c) lane_c->wait();
+    clk.join_wait += since(tj);
     for (PendingEdge& pe : pending_edges)
       if (pe.rel) edges.push_back(PGEdge{pe.i, pe.j, pe.rel->R_ji, pe.rel->t_ji, (int)pe.rel->inliers.size(), false});
     pending_edges.clear();
@@ -990,7 +1010,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       last_kf_frame = fi;
       // T:1820: local BA.  The point/observation gather reads kfs and map now; the device iterations refine a
       // private copy of the window poses on lane B and are written back at the next join.
+      const auto tg0 = Clock::now();
       pending_ba = GpuBundleAdjuster::gather(K, kfs, map, cfg.ba);
+      clk.ba_gather += since(tg0);
       if (lane) lane->submit([&ba, &pending_ba]() { ba.solve(pending_ba); });
       else ba.solve(pending_ba);
       if (!lane) join_lane();
@@ -1039,6 +1061,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     emit(fi);
   }
   join_lane();
+  if (lane) clk.lane_b_busy = lane->busy_seconds();
+  if (lane_c) clk.lane_c_busy = lane_c->busy_seconds();
   if (lane_c) {
     lane_clk.ransac += lane_c_clk.ransac; lane_clk.ransac_kernel_us += lane_c_clk.ransac_kernel_us; lane_clk.ransac_calls += lane_c_clk.ransac_calls;
     lane_clk.ransac_points += lane_c_clk.ransac_points; lane_clk.ransac_verified += lane_c_clk.ransac_verified;
@@ -1055,7 +1079,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   out.log = so.str();
   if (prefetch) {
     tracker.set_prefetcher(nullptr);
-    clk.shi_fallbacks += prefetch->replays();  // the worker's tie-order replays count too
+    clk.shi_fallbacks += prefetch->replays();
+    clk.shi_kernel_us += prefetch->kernel_us();
+    prefetch->busy(clk.pf_busy, clk.pf_gpu, clk.pf_replay);  // the worker's tie-order replays count too
     prefetch.reset();
   }
   clk.total = since(t_all);
@@ -1123,6 +1149,7 @@ struct sfmx_pipeline_stats {
   double us_klt_kernel, us_ransac_kernel, us_ba_kernel, us_shi_kernel;
   unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks, shi_calls, shi_memo_hits, shi_prefetched;
   double sec_shi_wait, sec_setup, sec_wall;
+  double sec_pf_busy, sec_pf_gpu, sec_pf_replay, sec_lane_b_busy, sec_lane_c_busy, sec_join_wait, sec_ba_gather;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -1167,7 +1194,8 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
       *stats = sfmx_pipeline_stats{(int)res.kfs.size(), (int)res.map.pts.size(), (int)res.edges.size(), std::min(pc.frames, n_images),
                                    c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host, c.shi_gpu, c.shi_replay, c.desc, c.bookkeeping, c.r_pre, c.r_gpu, c.r_verify, c.r_decomp, c.tri_iter, c.tri_solve, c.tri_insert,
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
-                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait, c.setup, wall};
+                                   c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait, c.setup, wall,
+                                   c.pf_busy, c.pf_gpu, c.pf_replay, c.lane_b_busy, c.lane_c_busy, c.join_wait, c.ba_gather};
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {
@@ -1186,6 +1214,22 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
 }
 
 // host-side math self-checks used by the CPU test-suite (no device involved)
+// Iteration order of an unordered_map<int,int> filled (and partly erased) with `keys`: default allocator vs the bump
+// arena.  ops[i] != 0 erases keys[i] instead of inserting it.  Returns the number of live entries written to each output.
+int sfmx_host_map_order(const int* keys, const unsigned char* ops, int n, int* order_default, int* order_arena) {
+  std::unordered_map<int, int> a;
+  sfmx_host::Arena arena;
+  sfmx_host::ArenaMap<int, int> b(0, std::hash<int>(), std::equal_to<int>(), sfmx_host::ArenaAlloc<std::pair<const int, int>>(&arena));
+  for (int i = 0; i < n; i++) {
+    if (ops && ops[i]) { a.erase(keys[i]); b.erase(keys[i]); }
+    else { a.emplace(keys[i], i); b.emplace(keys[i], i); }
+  }
+  int k = 0;
+  for (const auto& kv : a) order_default[k++] = kv.first;
+  int m = 0;
+  for (const auto& kv : b) order_arena[m++] = kv.first;
+  return k == m ? k : -1;
+}
 void sfmx_host_eight_point_E(const double* xn, const double* yn, const int* idx8, double* E9) {
   const sfmx_host::Mat3 E = sfmx_host::eight_point_E(xn, yn, idx8);
   std::memcpy(E9, E.a, 72);

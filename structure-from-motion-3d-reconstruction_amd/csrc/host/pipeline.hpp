@@ -71,6 +71,7 @@ struct StageClock {
   std::uint64_t lk_steps = 0, tracks_in = 0, ransac_calls = 0, ransac_points = 0, ba_calls = 0, ba_iters = 0, klt_calls = 0;
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
   double shi_wait = 0, setup = 0;
+  double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_b_busy = 0, lane_c_busy = 0, join_wait = 0, ba_gather = 0;
 };
 
 // shi_tomasi (T:237-302) on one context: device score + certain-outcome fixpoint (sfmx_shi_tomasi_candidates_pruned),
@@ -94,7 +95,7 @@ class CornerDetector {
 // The result is the uncapped accepted-corner sequence; GpuTracker::shi_tomasi takes prefixes of it.
 class CornerPrefetcher {
  public:
-  CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist, int workers);
+  CornerPrefetcher(int device, FrameSource& src, double quality, int min_dist, int workers, bool timing);
   ~CornerPrefetcher();
   CornerPrefetcher(const CornerPrefetcher&) = delete;
   CornerPrefetcher& operator=(const CornerPrefetcher&) = delete;
@@ -102,6 +103,8 @@ class CornerPrefetcher {
   bool take(int frame, std::vector<V2>& corners);   // waits for a requested frame; false if never requested / failed
   void discard_older_than(int frame);               // drop finished results of frames < frame that nobody took
   bool matches(double quality, int min_dist) const { return quality == quality_ && min_dist == min_dist_; }
+  double kernel_us();                               // accumulated device time of the workers' score kernels
+  void busy(double& total, double& gpu, double& replay);  // seconds over all workers (call after the run)
   std::uint64_t replays();                          // tie-order replays over all workers (call after the run)
 
  private:
@@ -111,6 +114,7 @@ class CornerPrefetcher {
     sfmx_pyramid* pyr = nullptr;
     std::unique_ptr<CornerDetector> det;
     StageClock clock;
+    double busy = 0;
     std::thread th;
   };
   void run(Worker& w);
@@ -263,9 +267,11 @@ class AsyncLane {
   sfmx_ctx* ctx() const { return ctx_; }
   void submit(std::function<void()> task);
   void wait();
+  double busy_seconds() const { return busy_seconds_; }  // time spent inside tasks (read while idle)
 
  private:
   void run();
+  double busy_seconds_ = 0;
   sfmx_ctx* ctx_ = nullptr;
   std::thread th_;
   std::mutex mu_;

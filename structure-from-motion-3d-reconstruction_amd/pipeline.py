@@ -34,7 +34,9 @@ class PipelineStats(ctypes.Structure):
                 ("ransac_calls", c_ulonglong), ("ransac_points", c_ulonglong), ("ba_calls", c_ulonglong),
                 ("ba_iters", c_ulonglong), ("ransac_verified", c_ulonglong), ("shi_fallbacks", c_ulonglong),
                 ("shi_calls", c_ulonglong), ("shi_memo_hits", c_ulonglong), ("shi_prefetched", c_ulonglong), ("sec_shi_wait", c_double),
-                ("sec_setup", c_double), ("sec_wall", c_double)]
+                ("sec_setup", c_double), ("sec_wall", c_double), ("sec_pf_busy", c_double), ("sec_pf_gpu", c_double),
+                ("sec_pf_replay", c_double), ("sec_lane_b_busy", c_double), ("sec_lane_c_busy", c_double),
+                ("sec_join_wait", c_double), ("sec_ba_gather", c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

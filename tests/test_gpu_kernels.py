@@ -202,6 +202,36 @@ def test_ba_build_and_step(ctx, golden, case):
     prob.close()
 
 
+def test_ba_full_size_c4(ctx):
+    """BASELINE config C4: W=10 poses, P=50 000 points seen in every pose (500 k residuals), N(0,0.5 px)
+    noise.  S, b and dx of one iteration must equal the oracle bit for bit at the full size, not only on small cases."""
+    W, P = 10, 50000
+    rng = np.random.default_rng(1)
+    pw = np.zeros((W, 12))
+    for k in range(W):
+        R, t = synth.ring_pose(2.0 * k)
+        pw[k, :9], pw[k, 9:] = R.ravel(), t
+    K = synth.K_TEMPLE
+    X = rng.normal(size=(P, 3)) * 0.08
+    ptr = np.arange(0, (P + 1) * W, W, dtype=np.int32)
+    li = np.tile(np.arange(W, dtype=np.int32), P)
+    Xc = np.einsum("kij,pj->pki", pw[:, :9].reshape(W, 3, 3), X) + pw[None, :, 9:]
+    uv = np.stack([K[0, 0] * Xc[..., 0] / Xc[..., 2] + K[0, 2], K[1, 1] * Xc[..., 1] / Xc[..., 2] + K[1, 2]], -1)
+    uv = np.ascontiguousarray((uv + rng.normal(size=uv.shape) * 0.5).reshape(P * W, 2))
+    prob = ctx.ba_problem(W, X, ptr, li, uv)
+    S, b = prob.build(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, True)
+    eS, eb = np.zeros((6 * W, 6 * W)), np.zeros(6 * W)
+    O.call("orc_ba_build", None, H.f64(pw), W, H.f64(X), P, ptr, li, H.f64(uv), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
+           float(K[1, 2]), 3.0, 1e-3, 1, eS, eb)
+    H.assert_bits_equal(S, eS, "S (C4)")
+    H.assert_bits_equal(b, eb, "b (C4)")
+    rc, dx = prob.step(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    erc, ex = H.solve_gauss(O, "orc", eS, eb)
+    assert rc == 0 and erc == 0
+    H.assert_bits_equal(dx, ex, "dx (C4)")
+    prob.close()
+
+
 def test_ba_edge_cases(ctx):
     """>16 observations (skipped, T:915), point behind a camera (T:933), singular Hpp (T:1012), duplicate pose."""
     rng = np.random.default_rng(4)

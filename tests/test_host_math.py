@@ -104,3 +104,20 @@ def test_introsort_replay_reproduces_std_sort_tie_order():
                     for b in range(a + 1, len(m)):
                         if scores[m[a]] == scores[m[b]]:
                             assert (pos_ref[m[a]] < pos_ref[m[b]]) == (pos_sel[m[a]] < pos_sel[m[b]]), (n, levels, rep)
+
+
+def test_arena_map_iterates_like_default_unordered_map():
+    """kf.obs / track_hist / map.pts live on a bump arena; their iteration order is part of the result (hazard H2) and
+    must be what libstdc++'s default-allocator unordered_map gives for the same insert/erase history."""
+    rng = np.random.default_rng(3)
+    fn = L.dll.sfmx_host_map_order
+    fn.restype = ctypes.c_int
+    for n, span, erase in [(10, 20, 0.0), (1000, 5000, 0.0), (20000, 30000, 0.2), (50000, 10**9, 0.1), (5000, 40, 0.5)]:
+        keys = rng.integers(0, span, n).astype(np.int32)
+        ops = (rng.random(n) < erase).astype(np.uint8)
+        a = np.full(n, -1, np.int32)
+        b = np.full(n, -2, np.int32)
+        k = fn(keys.ctypes.data_as(ctypes.c_void_p), ops.ctypes.data_as(ctypes.c_void_p), n, a.ctypes.data_as(ctypes.c_void_p),
+               b.ctypes.data_as(ctypes.c_void_p))
+        assert k >= 0
+        assert np.array_equal(a[:k], b[:k]), (n, span, erase)

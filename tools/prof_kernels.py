@@ -1,32 +1,29 @@
 #!/usr/bin/env python3
-"""Fixed small workload for rocprofv3 PMC passes: the three hot kernels at bench-like sizes.
+"""Fixed small workload for rocprofv3 PMC passes: the hot kernels at bench-like sizes.
 Usage (GPU box):  rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/prof_kernels.py"""
-import importlib, os, sys
-import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch  # noqa: F401  (one HIP runtime per process)
-PKG = "structure-from-motion-3d-reconstruction_amd"
-capi = importlib.import_module(PKG + ".capi"); synth = importlib.import_module(PKG + ".synth")
-import helpers as H
-ctx = capi.Context(0)
-O = H.oracle()
-seq = synth.make_sequence(2, 640, 480, 0.3, n_blobs=20000, seed=7)
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _inputs as I
+ctx = I.capi.Context(0)
+seq = I.synth.make_sequence(2, 640, 480, 0.3, n_blobs=20000, seed=7)
 a, b = seq["images"]
-pts = H.shi_tomasi(O, "orc", a, 2200, 0.01, 8)
 pa, pb = ctx.pyramid(a, 3), ctx.pyramid(b, 3)
+pts = I.corners(ctx, pa, 2200)
 for _ in range(5):
     fwd, back, keep, steps = ctx.klt_track(pa, pb, pts)
 print("klt tracks", len(pts), "lk_steps", steps)
-g = np.load(os.path.join(H.GOLDEN, "hotpath.npz"))
 N = 1100
-rng = np.random.default_rng(0)
-xi = np.tile(g["tv_xi"], (N // 240 + 1, 1))[:N] + rng.normal(size=(N, 2)) * 1e-4
-xj = np.tile(g["tv_xj"], (N // 240 + 1, 1))[:N] + rng.normal(size=(N, 2)) * 1e-4
-idx8 = H.uniform_draws(O, "orc", 12345, N, 8 * 2500).reshape(2500, 8)
+xi, xj = I.two_view(N)
+idx8 = I.octets(N, 2500)
 for _ in range(5):
     ctx.ransac_score(xi, xj, idx8, 1e-3)
 print("ransac N", N, "H 2500")
 for _ in range(3):
     ctx.shi_candidates_pruned(pa, 0.01, 8)
+pw, K, X, ptr, li, uv = I.ba_problem(6, 600)
+prob = ctx.ba_problem(6, X, ptr, li, uv)
+for _ in range(5):
+    prob.step(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+print("ba W 6 P 600")
+prob.close()
 ctx.close()
