@@ -36,6 +36,8 @@ typedef struct sfmx_pyramid sfmx_pyramid;
 
 /* ---- context ------------------------------------------------------------------------------ */
 int sfmx_ctx_create(int device_id, sfmx_ctx** out);
+/* same, with a stream priority hint: <0 high (short latency-critical launches), 0 normal, >0 low (background) */
+int sfmx_ctx_create_prio(int device_id, int priority, sfmx_ctx** out);
 void sfmx_ctx_destroy(sfmx_ctx* ctx);
 const char* sfmx_last_error(const sfmx_ctx* ctx);
 int sfmx_sync(sfmx_ctx* ctx);

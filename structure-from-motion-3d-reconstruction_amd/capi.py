@@ -18,7 +18,7 @@ SFMX_OK, SFMX_ERR_INVALID, SFMX_ERR_HIP, SFMX_ERR_NO_DEVICE, SFMX_ERR_SINGULAR, 
 
 # every symbol include/sfmx.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "sfmx_ctx_create", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_ctx_device", "sfmx_ctx_make_current", "sfmx_stream", "sfmx_set_timing", "sfmx_get_timing",
+    "sfmx_ctx_create", "sfmx_ctx_create_prio", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_ctx_device", "sfmx_ctx_make_current", "sfmx_stream", "sfmx_set_timing", "sfmx_get_timing",
     "sfmx_last_kernel_us", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
     "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",

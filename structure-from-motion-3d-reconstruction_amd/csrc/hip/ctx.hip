@@ -14,7 +14,9 @@ int sfmx_fail(sfmx_ctx* ctx, int status, const char* what, hipError_t e) {
 
 extern "C" {
 
-int sfmx_ctx_create(int device_id, sfmx_ctx** out) {
+int sfmx_ctx_create(int device_id, sfmx_ctx** out) { return sfmx_ctx_create_prio(device_id, 0, out); }
+
+int sfmx_ctx_create_prio(int device_id, int priority, sfmx_ctx** out) {
   if (!out) return SFMX_ERR_INVALID;
   *out = nullptr;
   int n = 0;
@@ -22,8 +24,12 @@ int sfmx_ctx_create(int device_id, sfmx_ctx** out) {
   if (hipSetDevice(device_id) != hipSuccess) return SFMX_ERR_NO_DEVICE;
   sfmx_ctx* c = new sfmx_ctx;
   c->device = device_id;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+  // priority: <0 latency-critical chains of tiny kernels (BA), >0 background work with large grids (corner prefetch)
+  int lo = 0, hi = 0;  // HIP: numerically lower = higher priority; range [hi, lo]
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  const int prio = priority < 0 ? hi : (priority > 0 ? lo : (lo + hi) / 2);
+  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return SFMX_ERR_HIP;

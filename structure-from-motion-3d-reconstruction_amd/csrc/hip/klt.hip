@@ -248,14 +248,16 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   c->resident_points = 0;
   // one device slab: [xy_in nb][fwd nb][back nb][steps 8][keep n]; one pinned slab for the upload and one
   // for the download, so a call costs two DMA transfers and one host synchronisation
-  const size_t o_fwd = nb, o_back = 2 * nb, o_steps = 3 * nb, o_keep = 3 * nb + 8, dev_bytes = o_keep + (size_t)n;
+  // device slab [xy_in nb][steps 8 (+8 pad)][fwd nb][back nb][keep n]: the upload covers the inputs and the zeroed
+  // step counter, the download everything behind it
+  const size_t o_steps = nb, o_fwd = nb + 16, o_back = o_fwd + nb, o_keep = o_back + nb, dev_bytes = o_keep + (size_t)n;
   SFMX_HIP(c, c->d[0].ensure(dev_bytes + 64));
-  SFMX_HIP(c, c->h[0].ensure(nb));
+  SFMX_HIP(c, c->h[0].ensure(nb + 16));
   SFMX_HIP(c, c->h[1].ensure(dev_bytes - nb));
   char* dbase = c->d[0].as<char>();
   memcpy(c->h[0].p, xy_in, nb);
-  SFMX_HIP(c, hipMemcpyAsync(dbase, c->h[0].p, nb, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemsetAsync(dbase + o_steps, 0, 8, c->stream));
+  memset(c->h[0].as<char>() + nb, 0, 16);
+  SFMX_HIP(c, hipMemcpyAsync(dbase, c->h[0].p, nb + 16, hipMemcpyHostToDevice, c->stream));
   const int r = cfg->win_radius, npix = (2 * r + 1) * (2 * r + 1), npad = (npix + 1) & ~1;
   const size_t shmem = (size_t)((2 * KLT_P * KLT_PS_FOR(r) + 3) & ~3) * sizeof(float) + (size_t)5 * npad * sizeof(double);
   KernelTimer t(c);
@@ -276,15 +278,15 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
 #undef KLT_LAUNCH
   t.stop();
   SFMX_HIP(c, hipGetLastError());
-  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, dbase + o_fwd, dev_bytes - nb, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, dbase + o_steps, dev_bytes - nb, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   t.collect();
-  const char* hp = c->h[1].as<char>();
-  memcpy(xy_fwd, hp, nb);
-  if (xy_back) memcpy(xy_back, hp + nb, nb);
+  const char* hp = c->h[1].as<char>();  // [steps 16][fwd nb][back nb][keep n]
   unsigned long long steps = 0;
-  memcpy(&steps, hp + 2 * nb, 8);
-  memcpy(keep, hp + 2 * nb + 8, (size_t)n);
+  memcpy(&steps, hp, 8);
+  memcpy(xy_fwd, hp + 16, nb);
+  if (xy_back) memcpy(xy_back, hp + 16 + nb, nb);
+  memcpy(keep, hp + 16 + 2 * nb, (size_t)n);
   if (n_steps_out) *n_steps_out = steps;
   return SFMX_OK;
 }

@@ -181,6 +181,16 @@ __device__ void rank2_project(double* E, double* A3, double* V3) {
     }
 }
 
+// one step of the 16-lane (value, code) arg-max all-reduce used by the Jacobi pivot search
+template <int CTRL>
+__device__ __forceinline__ void pivot_combine(double& v, int& code) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  const int oc = __builtin_amdgcn_update_dpp(0, code, CTRL, 0xF, 0xF, false);
+  const double ov = __hiloint2double(hi, lo);
+  if (ov > v || (ov == v && oc < code)) { v = ov; code = oc; }
+}
+
 struct HypLds {
   double D[72];   // 8x9 design matrix
   double A[81];   // AtA, rotated in place
@@ -227,36 +237,46 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
   // reference's row pass followed by a column pass: mathematically identical, two LDS round trips per
   // rotation instead of five.  These E's only RANK hypotheses (the winner is re-derived with libm on the
   // host), so last-bit differences from the reference's evaluation order are irrelevant here.
-  // Every lane of the group scans the 36 upper-triangle entries itself (LDS broadcast reads).
+  // Pivot search: lane t of the group owns upper-triangle entries t, t+16, t+32 (row-major numbering) and the 16
+  // lanes combine (|a|, code = 16*i + j) with a DPP all-reduce: larger |a| wins, equal |a| -> smaller code, which
+  // is exactly the reference's row-major scan with strict '>' (NaN never wins; an all-zero matrix ends the loop).
+  int own_off[3], own_code[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    int e = t + 16 * k, i = 0;
+    if (e > 35) e = 35;
+    while (e >= 8 - i) { e -= 8 - i; i++; }
+    const int j = i + 1 + e;
+    own_off[k] = i * 9 + j;
+    own_code[k] = 16 * i + j;
+  }
+  const bool third = t < 4;
   bool active = live;
   for (int it = 0; it < sweeps; ++it) {
     double bv = 0.0;
-    int p = 0, q = 1;
+    int code = 1;  // (0,1): the reference's initial p,q
     if (active) {
-      double u[36];
-      int n = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = i + 1; j < 9; j++) u[n++] = fabs(L.A[i * 9 + j]);
-      n = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++)
-#pragma unroll
-        for (int j = i + 1; j < 9; j++) {
-          if (u[n] > bv) { bv = u[n]; p = i; q = j; }  // NaN never wins, as in the reference's `v > maxv`
-          n++;
-        }
+      const double v0 = fabs(L.A[own_off[0]]), v1 = fabs(L.A[own_off[1]]), v2 = third ? fabs(L.A[own_off[2]]) : 0.0;
+      if (v0 > bv) { bv = v0; code = own_code[0]; }
+      if (v1 > bv) { bv = v1; code = own_code[1]; }
+      if (v2 > bv) { bv = v2; code = own_code[2]; }
     }
+    pivot_combine<0xB1>(bv, code);   // quad_perm [1,0,3,2]
+    pivot_combine<0x4E>(bv, code);   // quad_perm [2,3,0,1]
+    pivot_combine<0x141>(bv, code);  // row_half_mirror
+    pivot_combine<0x140>(bv, code);  // row_mirror
+    const int p = code >> 4, q = code & 15;
     if (active && bv < 1e-12) active = false;  // maxv < 1e-12 -> break
     if (!__any(active)) break;
     if (active) {
+      // all LDS reads of this rotation are issued together, ahead of the rotation-angle arithmetic
+      const int tr = t < 9 ? t : 8;
       const double app = L.A[p * 9 + p], aqq = L.A[q * 9 + q], apq = L.A[p * 9 + q];
+      const double vp = L.V[tr * 9 + p], vq = L.V[tr * 9 + q];
+      const double akp = L.A[tr * 9 + p], akq = L.A[tr * 9 + q];
       const Rot r = half_angle_fast(2.0 * apq, aqq - app);
       const double c = r.c, s = r.s;
       if (t < 9) {
-        const double vp = L.V[t * 9 + p], vq = L.V[t * 9 + q];
-        const double akp = L.A[t * 9 + p], akq = L.A[t * 9 + q];
         L.V[t * 9 + p] = c * vp - s * vq;
         L.V[t * 9 + q] = s * vp + c * vq;
         if (t != p && t != q) {
@@ -379,9 +399,8 @@ int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, co
                       int32_t* counts_out, int32_t* best_iter, int32_t* best_count, double* E_out) {
   SFMX_REQUIRE(c, c && xi && xj && idx8 && n >= 8 && H > 0 && best_iter && best_count);
   const size_t pb = (size_t)n * 16, ib = (size_t)H * 32;
-  SFMX_HIP(c, c->d[0].ensure(pb));
-  SFMX_HIP(c, c->d[1].ensure(pb));
-  SFMX_HIP(c, c->d[2].ensure(ib));
+  // one device slab [xi pb][xj pb][idx8 ib] filled by ONE transfer from the pinned staging slab
+  SFMX_HIP(c, c->d[0].ensure(2 * pb + ib));
   SFMX_HIP(c, c->d[3].ensure((size_t)H * 72));
   SFMX_HIP(c, c->d[4].ensure((size_t)H * 4 + 64));   // [counts H*4][best_iter, best_count]
   SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
@@ -391,17 +410,16 @@ int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, co
   memcpy(hin, xi, pb);
   memcpy(hin + pb, xj, pb);
   memcpy(hin + 2 * pb, idx8, ib);
-  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, hin, pb, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, hin + pb, pb, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(c->d[2].p, hin + 2 * pb, ib, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, hin, 2 * pb + ib, hipMemcpyHostToDevice, c->stream));
   c->resident_points = n;
+  const double* d_xi = c->d[0].as<double>();
+  const double* d_xj = reinterpret_cast<const double*>(c->d[0].as<char>() + pb);
+  const int32_t* d_idx = reinterpret_cast<const int32_t*>(c->d[0].as<char>() + 2 * pb);
   int32_t* d_best = c->d[4].as<int32_t>() + H;
   KernelTimer t(c);
   t.start();
-  k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[2].as<int32_t>(), H, 120,
-                                                        c->d[3].as<double>());
-  k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, c->d[3].as<double>(), H,
-                                                              thr, c->d[4].as<int32_t>());
+  k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(d_xi, d_xj, n, d_idx, H, 120, c->d[3].as<double>());
+  k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, c->d[3].as<double>(), H, thr, c->d[4].as<int32_t>());
   k_argmax<<<1, 256, 0, c->stream>>>(c->d[4].as<int32_t>(), H, d_best);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
@@ -425,17 +443,18 @@ int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, co
   const size_t pb = (size_t)n * 16;
   SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
   SFMX_HIP(c, c->h[2].ensure((size_t)n + 64));
-  if (xi) {
-    SFMX_HIP(c, c->d[0].ensure(pb));
-    SFMX_HIP(c, c->d[1].ensure(pb));
+  if (xi) {  // same layout as sfmx_ransac_score leaves behind: [xi pb][xj pb]
+    SFMX_HIP(c, c->d[0].ensure(2 * pb));
     SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, xi, pb, hipMemcpyHostToDevice, c->stream));
-    SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, xj, pb, hipMemcpyHostToDevice, c->stream));
+    SFMX_HIP(c, hipMemcpyAsync(c->d[0].as<char>() + pb, xj, pb, hipMemcpyHostToDevice, c->stream));
     c->resident_points = n;
   }
+  const double* d_xi = c->d[0].as<double>();
+  const double* d_xj = reinterpret_cast<const double*>(c->d[0].as<char>() + pb);
   E9 E;
   memcpy(E.e, E9in, 72);
   uint8_t* d_mask = c->d[5].as<uint8_t>() + 64;
-  k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(c->d[0].as<double>(), c->d[1].as<double>(), n, E, thr, d_mask);
+  k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(d_xi, d_xj, n, E, thr, d_mask);
   SFMX_HIP(c, hipGetLastError());
   SFMX_HIP(c, hipMemcpyAsync(c->h[2].p, d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));

@@ -80,22 +80,19 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
   return out;
 }
 
-std::vector<V2> CornerDetector::detect(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist) {
-  const auto t0 = Clock::now();
-  int w = 0, h = 0;
-  sfmx_pyramid_level_size(pyr, 0, &w, &h);
-  const int cap = w * h;
-  if ((int)cand_xy_.size() < cap) { cand_xy_.resize((size_t)cap); cand_s_.resize((size_t)cap); }
-  struct Cand { int x, y; double s; int idx; };
-  const double md2 = (double)min_dist * min_dist;
-  const int cell = std::max(1, min_dist);
-  const int gw = w / cell + 1, gh = h / cell + 1;
-  std::vector<int> head((size_t)gw * gh, -1), next;
-  std::vector<V2> out;
-  out.reserve((size_t)std::max(0, max_corners));
-  // "is c closer than min_dist to an accepted corner?" (T:292-296) -- an existence test, so a uniform
-  // grid over the accepted corners answers it exactly like the reference's linear scan.
-  auto blocked = [&](const Cand& c) {
+namespace {
+struct Cand { int x, y; double s; int idx; };
+
+// The accepted corners plus a uniform grid over them.  "Is c closer than min_dist to an accepted corner?" (T:292-296)
+// is an existence test, so the grid answers it exactly like the reference's linear scan.
+struct GreedyGrid {
+  int cell, gw, gh;
+  double md2;
+  std::vector<int> head, next;
+  std::vector<V2>& out;
+  GreedyGrid(int w, int h, int min_dist, std::vector<V2>& o)
+      : cell(std::max(1, min_dist)), gw(w / cell + 1), gh(h / cell + 1), md2((double)min_dist * min_dist), head((size_t)gw * gh, -1), out(o) {}
+  bool blocked(const Cand& c) const {
     const int cx = c.x / cell, cy = c.y / cell;
     for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1); gy++)
       for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1); gx++)
@@ -104,119 +101,218 @@ std::vector<V2> CornerDetector::detect(sfmx_pyramid* pyr, int max_corners, doubl
           if (dx * dx + dy * dy < md2) return true;
         }
     return false;
-  };
-  auto accept = [&](const Cand& c) {
+  }
+  void accept(const Cand& c) {
     const int cx = c.x / cell, cy = c.y / cell;
     next.push_back(head[(size_t)cy * gw + cx]);
     head[(size_t)cy * gw + cx] = (int)out.size();
     out.push_back(V2{double(c.x), double(c.y)});
-  };
-
-  static const bool force_full = std::getenv("SFMX_SHI_FULL_SORT") != nullptr;  // test hook: always take the exact slow path
-  bool done = false;
-  if (!force_full && min_dist >= 1 && min_dist <= 16) {
-    // ---- fast path: the device has already removed every candidate that is certainly rejected
-    int n = 0, n_total = 0;
-    double maxv = 0;
-    if ((int)cand_full_.size() < cap) cand_full_.resize((size_t)cap);
-    check(ctx_, sfmx_shi_tomasi_candidates_pruned(ctx_, pyr, quality, min_dist, cap, cand_xy_.data(), cand_s_.data(), cand_full_.data(), &n,
-                                                  &n_total, &maxv),
-          "shi_tomasi_candidates_pruned");
-    if (clk_) { clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_); clk_->shi_gpu += since(t0); }
-    std::vector<Cand> cands((size_t)n);
-    for (int i = 0; i < n; i++)
-      cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0x7fffu), (int)((cand_xy_[(size_t)i] >> 16) & 0x7fffu), cand_s_[(size_t)i], i};
-    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s || (a.s == b.s && a.idx < b.idx); });
-    // Walk score groups.  A group with a single member behaves as in the reference.  For a group of
-    // equal scores the reference's order is whatever its std::sort produced; the outcome is independent
-    // of that order iff at most ONE member is still eligible (not blocked by corners of strictly higher
-    // score) -- then exactly that member is accepted.  Two or more eligible members: ambiguous => redo
-    // with the full candidate list and the reference's own sort call.
-    auto walk = [&](bool& ambiguous) {
-      ambiguous = false;
-      size_t i = 0;
-      while (i < cands.size() && (int)out.size() < std::max(1, max_corners)) {
-        size_t j = i + 1;
-        while (j < cands.size() && cands[j].s == cands[i].s) j++;
-        if (j - i == 1) {
-          if (!blocked(cands[i])) accept(cands[i]);
-        } else {
-          int eligible = -1, count = 0;
-          for (size_t k = i; k < j; k++)
-            if (!blocked(cands[k])) { count++; eligible = (int)k; }
-          if (count >= 2) { ambiguous = true; return; }
-          if (count == 1) accept(cands[(size_t)eligible]);
-        }
-        i = j;
-        if ((int)out.size() >= max_corners) break;
-      }
-    };
-    bool ambiguous = false;
-    walk(ambiguous);
-    done = !ambiguous;
-    if (ambiguous) {
-      // ---- tie order from a selective replay of libstdc++'s introsort on the FULL candidate list
-      if (clk_) clk_->shi_fallbacks++;
-      const auto tr0 = Clock::now();
-      // The sort keys of ALL candidates were downloaded speculatively into pinned memory by the device call;
-      // survivors know their index in that list.  The replay runs in place on that buffer.
-      const int nf = n_total;
-      void* kp = nullptr;
-      check(ctx_, sfmx_shi_tomasi_fetch_all_keys(ctx_, nf, &kp), "shi_tomasi_fetch_all_keys");
-      static_assert(sizeof(SortKey) == 16, "SortKey must match the device record {double, u32, u32}");
-      SortKey* keys = static_cast<SortKey*>(kp);
-      std::vector<Cand> pruned((size_t)n);
-      for (int k = 0; k < n; k++)
-        pruned[(size_t)k] = {(int)(cand_xy_[(size_t)k] & 0x7fffu), (int)((cand_xy_[(size_t)k] >> 16) & 0x7fffu), cand_s_[(size_t)k], k};
-      // interesting = survivors that share their score with another survivor
-      for (size_t a = 0; a + 1 < cands.size(); a++)
-        if (cands[a].s == cands[a + 1].s) {
-          keys[(size_t)cand_full_[(size_t)cands[a].idx]].mark = 1;
-          keys[(size_t)cand_full_[(size_t)cands[a + 1].idx]].mark = 1;
-        }
-      const std::vector<std::int32_t>& full_of = cand_full_;
-      if (introsort_replay_selective(keys, (size_t)nf)) {
-        // positions of the marked elements after the replay (only those are ever compared)
-        std::unordered_map<int, int> pos;
-        for (int f = 0; f < nf; f++)
-          if (keys[(size_t)f].mark) pos.emplace((int)keys[(size_t)f].id, f);
-        cands = pruned;
-        std::sort(cands.begin(), cands.end(), [&](const Cand& a, const Cand& b) {
-          if (a.s != b.s) return a.s > b.s;
-          return pos.at(full_of[(size_t)a.idx]) < pos.at(full_of[(size_t)b.idx]);  // equal scores => both are marked
-        });
-        out.clear();
-        next.clear();
-        std::fill(head.begin(), head.end(), -1);
-        for (const Cand& c : cands) {  // the order is now the reference's: plain greedy (T:290-300)
-          if (blocked(c)) continue;
-          accept(c);
-          if ((int)out.size() >= max_corners) break;
-        }
-        done = true;
-      }
-      if (clk_) clk_->shi_replay += since(tr0);
-    }
   }
-  if (!done) {
-    // ---- exact slow path: every candidate, the reference's sort call on the reference's input order
-    out.clear();
-    next.clear();
-    std::fill(head.begin(), head.end(), -1);
-    int n = 0;
-    double maxv = 0;
-    check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &n, &maxv), "shi_tomasi_candidates");
-    if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
-    std::vector<Cand> cands((size_t)n);
-    for (int i = 0; i < n; i++) cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0xffffu), (int)(cand_xy_[(size_t)i] >> 16), cand_s_[(size_t)i], i};
-    std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s; });  // T:286
+  void greedy(const std::vector<Cand>& cands, int max_corners) {  // T:290-300 on an already ordered list
     for (const Cand& c : cands) {
       if (blocked(c)) continue;
       accept(c);
       if ((int)out.size() >= max_corners) break;
     }
   }
+};
+
+void unpack_survivors(const std::uint32_t* xy, const double* s, int n, std::vector<Cand>& cands) {
+  cands.resize((size_t)n);
+  for (int i = 0; i < n; i++) cands[(size_t)i] = {(int)(xy[i] & 0x7fffu), (int)((xy[i] >> 16) & 0x7fffu), s[i], i};
+}
+
+// Walk score groups of the survivors (sorted by descending score).  A group with a single member behaves as in the
+// reference.  For a group of equal scores the reference's order is whatever its std::sort produced; the outcome is
+// independent of that order iff at most ONE member is still eligible (not blocked by corners of strictly higher
+// score) -- then exactly that member is accepted.  Two or more eligible members: ambiguous => false.
+bool walk_tie_free(const std::vector<Cand>& cands, GreedyGrid& g, int max_corners) {
+  size_t i = 0;
+  while (i < cands.size() && (int)g.out.size() < std::max(1, max_corners)) {
+    size_t j = i + 1;
+    while (j < cands.size() && cands[j].s == cands[i].s) j++;
+    if (j - i == 1) {
+      if (!g.blocked(cands[i])) g.accept(cands[i]);
+    } else {
+      int eligible = -1, count = 0;
+      for (size_t k = i; k < j; k++)
+        if (!g.blocked(cands[k])) { count++; eligible = (int)k; }
+      if (count >= 2) return false;
+      if (count == 1) g.accept(cands[(size_t)eligible]);
+    }
+    i = j;
+    if ((int)g.out.size() >= max_corners) break;
+  }
+  return true;
+}
+}  // namespace
+
+bool CornerDetector::detect_device(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist, std::vector<V2>& out, CornerTies& ties) {
+  const auto t0 = Clock::now();
+  int w = 0, h = 0;
+  sfmx_pyramid_level_size(pyr, 0, &w, &h);
+  const int cap = w * h;
+  static const bool force_full = std::getenv("SFMX_SHI_FULL_SORT") != nullptr;  // test hook: always take the exact slow path
+  out.clear();
+  if (force_full || min_dist < 1 || min_dist > 16) {
+    out = detect_full_sort(pyr, max_corners, quality, min_dist);
+    return true;
+  }
+  if ((int)cand_xy_.size() < cap) { cand_xy_.resize((size_t)cap); cand_s_.resize((size_t)cap); cand_full_.resize((size_t)cap); }
+  // the device has already removed every candidate that is certainly rejected
+  int n = 0, n_total = 0;
+  double maxv = 0;
+  check(ctx_, sfmx_shi_tomasi_candidates_pruned(ctx_, pyr, quality, min_dist, cap, cand_xy_.data(), cand_s_.data(), cand_full_.data(), &n,
+                                                &n_total, &maxv),
+        "shi_tomasi_candidates_pruned");
+  if (clk_) { clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_); clk_->shi_gpu += since(t0); }
+  std::vector<Cand> cands;
+  unpack_survivors(cand_xy_.data(), cand_s_.data(), n, cands);
+  std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s || (a.s == b.s && a.idx < b.idx); });
+  out.reserve((size_t)std::min(std::max(0, max_corners), n));
+  GreedyGrid g(w, h, min_dist, out);
+  if (walk_tie_free(cands, g, max_corners)) return true;
+  // ---- the tie order matters: hand the survivors and the sort keys of ALL candidates to resolve_ties().  The keys
+  // were downloaded speculatively into pinned memory by the device call; take a private copy so that the context
+  // can start on the next image.
+  if (clk_) clk_->shi_fallbacks++;
+  const auto tk0 = Clock::now();
+  void* kp = nullptr;
+  check(ctx_, sfmx_shi_tomasi_fetch_all_keys(ctx_, n_total, &kp), "shi_tomasi_fetch_all_keys");
+  static_assert(sizeof(SortKey) == 16, "SortKey must match the device record {double, u32, u32}");
+  if ((int)ties.keys.size() < n_total) ties.keys.resize((size_t)n_total + (size_t)n_total / 8);
+  std::memcpy(ties.keys.data(), kp, (size_t)n_total * sizeof(SortKey));
+  ties.w = w; ties.h = h; ties.min_dist = min_dist; ties.max_corners = max_corners; ties.n_total = n_total;
+  ties.xy.assign(cand_xy_.begin(), cand_xy_.begin() + n);
+  ties.s.assign(cand_s_.begin(), cand_s_.begin() + n);
+  ties.full.assign(cand_full_.begin(), cand_full_.begin() + n);
+  if (clk_) clk_->shi_gpu += since(tk0);
+  out.clear();
+  return false;
+}
+
+bool CornerDetector::resolve_ties(CornerTies& ties, std::vector<V2>& out, StageClock* clk) {
+  // tie order from a selective replay of libstdc++'s introsort on the FULL candidate list (introsort_replay.hpp)
+  const auto tr0 = Clock::now();
+  const int n = (int)ties.xy.size(), nf = ties.n_total;
+  SortKey* keys = ties.keys.data();
+  std::vector<Cand> cands;
+  unpack_survivors(ties.xy.data(), ties.s.data(), n, cands);
+  std::vector<Cand> by_score = cands;
+  std::sort(by_score.begin(), by_score.end(), [](const Cand& a, const Cand& b) { return a.s > b.s || (a.s == b.s && a.idx < b.idx); });
+  // interesting = survivors that share their score with another survivor
+  for (size_t a = 0; a + 1 < by_score.size(); a++)
+    if (by_score[a].s == by_score[a + 1].s) {
+      keys[(size_t)ties.full[(size_t)by_score[a].idx]].mark = 1;
+      keys[(size_t)ties.full[(size_t)by_score[a + 1].idx]].mark = 1;
+    }
+  bool ok = introsort_replay_selective(keys, (size_t)nf);
+  if (ok) {
+    // positions of the marked elements after the replay (only those are ever compared)
+    std::unordered_map<int, int> pos;
+    for (int f = 0; f < nf; f++)
+      if (keys[(size_t)f].mark) pos.emplace((int)keys[(size_t)f].id, f);
+    const std::vector<std::int32_t>& full_of = ties.full;
+    std::sort(cands.begin(), cands.end(), [&](const Cand& a, const Cand& b) {
+      if (a.s != b.s) return a.s > b.s;
+      return pos.at(full_of[(size_t)a.idx]) < pos.at(full_of[(size_t)b.idx]);  // equal scores => both are marked
+    });
+    out.clear();
+    GreedyGrid g(ties.w, ties.h, ties.min_dist, out);
+    g.greedy(cands, ties.max_corners);  // the order is now the reference's: plain greedy (T:290-300)
+  }
+  if (clk) clk->shi_replay += since(tr0);
+  return ok;
+}
+
+// exact slow path: every candidate, the reference's sort call on the reference's input order
+std::vector<V2> CornerDetector::detect_full_sort(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist) {
+  int w = 0, h = 0;
+  sfmx_pyramid_level_size(pyr, 0, &w, &h);
+  const int cap = w * h;
+  if ((int)cand_xy_.size() < cap) { cand_xy_.resize((size_t)cap); cand_s_.resize((size_t)cap); cand_full_.resize((size_t)cap); }
+  int n = 0;
+  double maxv = 0;
+  check(ctx_, sfmx_shi_tomasi_candidates(ctx_, pyr, quality, cap, cand_xy_.data(), cand_s_.data(), &n, &maxv), "shi_tomasi_candidates");
+  if (clk_) clk_->shi_kernel_us += sfmx_last_kernel_us(ctx_);
+  std::vector<Cand> cands((size_t)n);
+  for (int i = 0; i < n; i++) cands[(size_t)i] = {(int)(cand_xy_[(size_t)i] & 0xffffu), (int)(cand_xy_[(size_t)i] >> 16), cand_s_[(size_t)i], i};
+  std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.s > b.s; });  // T:286
+  std::vector<V2> out;
+  out.reserve((size_t)std::max(0, max_corners));
+  GreedyGrid g(w, h, min_dist, out);
+  g.greedy(cands, max_corners);
   return out;
+}
+
+std::vector<V2> CornerDetector::detect(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist) {
+  std::vector<V2> out;
+  if (detect_device(pyr, max_corners, quality, min_dist, out, ties_)) return out;
+  if (resolve_ties(ties_, out, clk_)) return out;
+  return detect_full_sort(pyr, max_corners, quality, min_dist);  // the replay declined (depth limit): last resort
+}
+
+// ------------------------------------------------------------------------------------------ context pool
+ContextPool& ContextPool::instance() {
+  static ContextPool* p = new ContextPool;  // leaked on purpose, see pipeline.hpp
+  return *p;
+}
+PooledCtx* ContextPool::acquire(int device, int priority) {
+  static const bool no_pool = std::getenv("SFMX_NO_CTX_POOL") != nullptr;
+  if (!no_pool) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (size_t i = 0; i < free_.size(); i++)
+      if (free_[i]->device == device && free_[i]->priority == priority) {
+        PooledCtx* pc = free_[i];
+        free_.erase(free_.begin() + (long)i);
+        return pc;
+      }
+  }
+  auto pc = std::make_unique<PooledCtx>();
+  pc->device = device;
+  pc->priority = priority;
+  check(nullptr, sfmx_ctx_create_prio(device, priority, &pc->ctx), "ctx_create(helper)");
+  return pc.release();
+}
+void ContextPool::release(PooledCtx* pc) {
+  if (!pc) return;
+  static const bool no_pool = std::getenv("SFMX_NO_CTX_POOL") != nullptr;
+  (void)sfmx_sync(pc->ctx);
+  (void)sfmx_set_timing(pc->ctx, 0);
+  if (no_pool) {
+    if (pc->pyr) sfmx_pyramid_destroy(pc->ctx, pc->pyr);
+    sfmx_ctx_destroy(pc->ctx);
+    delete pc;
+    return;
+  }
+  std::lock_guard<std::mutex> lk(mu_);
+  free_.push_back(pc);
+}
+void ContextPool::clear() {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (PooledCtx* pc : free_) {
+    if (pc->pyr) sfmx_pyramid_destroy(pc->ctx, pc->pyr);
+    sfmx_ctx_destroy(pc->ctx);
+    delete pc;
+  }
+  free_.clear();
+}
+sfmx_pyramid* PooledCtx::pyramid(int w, int h, int levels) {
+  if (pyr && (pw != w || ph != h || pl != levels)) {
+    sfmx_pyramid_destroy(ctx, pyr);
+    pyr = nullptr;
+  }
+  if (!pyr) {
+    check(ctx, sfmx_pyramid_create(ctx, w, h, levels, &pyr), "pyramid_create(helper)");
+    pw = w; ph = h; pl = levels;
+  }
+  return pyr;
+}
+
+// stream priority of a helper context: default, overridable for experiments (-1 high, 0 normal, 1 low)
+static int prio_env(const char* name, int dflt) {
+  if (const char* e = std::getenv(name)) return std::atoi(e);
+  return dflt;
 }
 
 // ------------------------------------------------------------------------------------------ prefetcher
@@ -225,14 +321,19 @@ CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality,
   try {
     for (int i = 0; i < std::max(1, workers); ++i) {
       auto w = std::make_unique<Worker>();
-      check(nullptr, sfmx_ctx_create(device, &w->ctx), "ctx_create(prefetch)");
+      w->pc = ContextPool::instance().acquire(device, prio_env("SFMX_PRIO_PREFETCH", 0));
+      w->ctx = w->pc->ctx;
       workers_.push_back(std::move(w));
       Worker& ww = *workers_.back();
-      check(ww.ctx, sfmx_pyramid_create(ww.ctx, src.width(), src.height(), 1, &ww.pyr), "pyramid_create(prefetch)");
+      ww.pyr = ww.pc->pyramid(src.width(), src.height(), 1);
       if (timing) (void)sfmx_set_timing(ww.ctx, 1);
       ww.det = std::make_unique<CornerDetector>(ww.ctx, &ww.clock);
     }
-    for (auto& w : workers_) w->th = std::thread([this, p = w.get()] { run(*p); });
+    for (auto& w : workers_) {
+      for (auto& b : w->ties) w->free_ties.push_back(&b);
+      w->th = std::thread([this, p = w.get()] { run(*p); });
+      w->th_resolver = std::thread([this, p = w.get()] { run_resolver(*p); });
+    }
   } catch (...) {
     shutdown();
     throw;
@@ -244,18 +345,19 @@ void CornerPrefetcher::shutdown() {
     stop_ = true;
   }
   cv_req_.notify_all();
+  for (auto& w : workers_) w->cv_ties.notify_all();
   for (auto& w : workers_) {
     if (w->th.joinable()) w->th.join();
+    if (w->th_resolver.joinable()) w->th_resolver.join();
     w->det.reset();
-    if (w->pyr) sfmx_pyramid_destroy(w->ctx, w->pyr);
-    if (w->ctx) sfmx_ctx_destroy(w->ctx);
+    ContextPool::instance().release(w->pc);
   }
   workers_.clear();
 }
 CornerPrefetcher::~CornerPrefetcher() { shutdown(); }
 void CornerPrefetcher::busy(double& total, double& gpu, double& replay) {
   std::lock_guard<std::mutex> lk(mu_);
-  for (auto& w : workers_) { total += w->busy; gpu += w->clock.shi_gpu; replay += w->clock.shi_replay; }
+  for (auto& w : workers_) { total += w->busy; gpu += w->clock.shi_gpu; replay += w->busy_resolver; }
 }
 double CornerPrefetcher::kernel_us() {
   double us = 0;
@@ -274,7 +376,7 @@ void CornerPrefetcher::request(int frame) {
     slots_.emplace(frame, Slot{});
     queue_.push_back(frame);
   }
-  cv_req_.notify_one();
+  cv_req_.notify_all();
 }
 void CornerPrefetcher::discard_older_than(int frame) {
   std::lock_guard<std::mutex> lk(mu_);
@@ -293,37 +395,80 @@ bool CornerPrefetcher::take(int frame, std::vector<V2>& corners) {
   slots_.erase(frame);
   return ok;
 }
+void CornerPrefetcher::publish(int frame, std::vector<V2>&& seq, bool failed) {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = slots_.find(frame);
+    if (it != slots_.end()) {
+      it->second.corners = std::move(seq);
+      it->second.failed = failed;
+      it->second.done = true;
+    }
+  }
+  cv_done_.notify_all();
+}
+
+// device thread of a worker: image -> device score + fixpoint -> tie-free walk; ties go to the resolver thread
 void CornerPrefetcher::run(Worker& w) {
   (void)sfmx_ctx_make_current(w.ctx);  // HIP's current device is per thread
   for (;;) {
     int frame;
+    CornerTies* buf = nullptr;
     {
       std::unique_lock<std::mutex> lk(mu_);
-      cv_req_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+      cv_req_.wait(lk, [&] { return stop_ || (!queue_.empty() && !w.free_ties.empty()); });
       if (stop_) return;
       frame = queue_.front();
       queue_.pop_front();
+      buf = w.free_ties.back();
+      w.free_ties.pop_back();
     }
     std::vector<V2> seq;
-    bool failed = false;
+    bool failed = false, final = true;
     const auto tb = Clock::now();
     try {
       src_.load(w.ctx, frame, w.pyr);
-      seq = w.det->detect(w.pyr, 0x3fffffff, quality_, min_dist_);  // uncapped: every later request is a prefix
+      final = w.det->detect_device(w.pyr, 0x3fffffff, quality_, min_dist_, seq, *buf);  // uncapped: every later request is a prefix
     } catch (...) {
       failed = true;  // the main thread recomputes synchronously and reports the error where the reference would
     }
     {
       std::lock_guard<std::mutex> lk(mu_);
       w.busy += since(tb);
-      auto it = slots_.find(frame);
-      if (it != slots_.end()) {
-        it->second.corners = std::move(seq);
-        it->second.failed = failed;
-        it->second.done = true;
-      }
+      if (failed || final) w.free_ties.push_back(buf);
+      else w.ties_queue.push_back({frame, buf});
     }
-    cv_done_.notify_all();
+    if (failed || final) publish(frame, std::move(seq), failed);
+    else w.cv_ties.notify_one();
+  }
+}
+
+// resolver thread of a worker: pure host work (introsort replay + greedy pick), no device access
+void CornerPrefetcher::run_resolver(Worker& w) {
+  for (;;) {
+    std::pair<int, CornerTies*> job;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      w.cv_ties.wait(lk, [&] { return stop_ || !w.ties_queue.empty(); });
+      if (stop_) return;
+      job = w.ties_queue.front();
+      w.ties_queue.pop_front();
+    }
+    std::vector<V2> seq;
+    bool ok = false;
+    const auto tb = Clock::now();
+    try {
+      ok = CornerDetector::resolve_ties(*job.second, seq, &w.clock_resolver);
+    } catch (...) {
+      ok = false;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      w.busy_resolver += since(tb);
+      w.free_ties.push_back(job.second);
+    }
+    cv_req_.notify_all();  // a tie buffer is free again
+    publish(job.first, std::move(seq), !ok);  // !ok: the replay declined -> the consumer detects synchronously
   }
 }
 
@@ -395,15 +540,18 @@ StepOut GpuTracker::step(FrameSource& src, int fi) {
     // grid over track positions gives the same answer as the reference's linear scan.
     const int cell = std::max(1, cfg_.min_distance);
     const int gw = w_ / cell + 3, gh = h_ / cell + 3;  // one guard cell around the image
-    std::vector<std::vector<int>> grid((size_t)gw * gh);
+    grid_head_.assign((size_t)gw * gh, -1);  // per-cell singly linked lists through grid_next_ (no per-cell allocations)
+    grid_next_.clear();
+    grid_next_.reserve((size_t)cfg_.max_tracks);
     auto cell_of = [&](double v, int lim) -> int {
       if (!(v > -(double)cell && v < (double)(lim + cell))) return -1;  // farther than min_distance from any pixel (or NaN)
       return (int)std::floor(v / cell) + 1;
     };
-    auto insert = [&](int ti) {
+    auto insert = [&](int ti) {  // ti == grid_next_.size(): tracks are inserted in index order
       const int gx = cell_of(tracks_[(size_t)ti].p.x, w_), gy = cell_of(tracks_[(size_t)ti].p.y, h_);
-      if (gx < 0 || gy < 0 || gx >= gw || gy >= gh) return;
-      grid[(size_t)gy * gw + gx].push_back(ti);
+      if (gx < 0 || gy < 0 || gx >= gw || gy >= gh) { grid_next_.push_back(-2); return; }
+      grid_next_.push_back(grid_head_[(size_t)gy * gw + gx]);
+      grid_head_[(size_t)gy * gw + gx] = ti;
     };
     for (int i = 0; i < (int)tracks_.size(); i++) insert(i);
     const double md2 = (double)cfg_.min_distance * cfg_.min_distance;
@@ -412,7 +560,7 @@ StepOut GpuTracker::step(FrameSource& src, int fi) {
       const int cx = (int)p.x / cell + 1, cy = (int)p.y / cell + 1;
       for (int gy = std::max(0, cy - 1); gy <= std::min(gh - 1, cy + 1) && ok; gy++)
         for (int gx = std::max(0, cx - 1); gx <= std::min(gw - 1, cx + 1) && ok; gx++)
-          for (int ti : grid[(size_t)gy * gw + gx]) {
+          for (int ti = grid_head_[(size_t)gy * gw + gx]; ti >= 0; ti = grid_next_[(size_t)ti]) {
             const double dx = tracks_[(size_t)ti].p.x - p.x, dy = tracks_[(size_t)ti].p.y - p.y;
             if (dx * dx + dy * dy < md2) { ok = false; break; }
           }
@@ -656,8 +804,9 @@ void GpuBundleAdjuster::apply(const BaJob& job, std::vector<Keyframe>& kfs) {
 }
 
 // ------------------------------------------------------------------------------------------ async lane
-AsyncLane::AsyncLane(int device) {
-  check(nullptr, sfmx_ctx_create(device, &ctx_), "ctx_create(lane)");
+AsyncLane::AsyncLane(int device, int priority) {
+  pc_ = ContextPool::instance().acquire(device, priority);
+  ctx_ = pc_->ctx;
   th_ = std::thread([this] { run(); });
 }
 AsyncLane::~AsyncLane() {
@@ -667,7 +816,7 @@ AsyncLane::~AsyncLane() {
   }
   cv_task_.notify_all();
   if (th_.joinable()) th_.join();
-  sfmx_ctx_destroy(ctx_);
+  ContextPool::instance().release(pc_);
 }
 void AsyncLane::submit(std::function<void()> task) {
   {
@@ -815,8 +964,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   StageClock lane_clk, lane_c_clk;
   std::unique_ptr<AsyncLane> lane, lane_c;
   if (use_lane) {
-    lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
-    lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx));
+    lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_B", 0));
+    lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_C", 0));
   }
   if (sfmx_get_timing(ctx)) {  // per-kernel event timing is inherited by the helper contexts
     if (lane) (void)sfmx_set_timing(lane->ctx(), 1);
@@ -888,10 +1037,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     if (pending_loop.active && fi >= pending_loop.frame + 2) join_lane();  // its 'current' pyramid is about to be reused
     if (prefetch) {
       prefetch->discard_older_than(fi);  // results nobody asked for (no replenish on that frame)
-      for (int a = 1; a <= prefetch_workers; ++a)  // one frame in flight per worker, overlapping this frame's work
+      for (int a = 1; a <= prefetch_workers + 1; ++a)  // per worker one image on the device and one in tie resolution
         if (fi + a < std::min(frames, src.count())) prefetch->request(fi + a);
     }
+    const auto tm0 = Clock::now();
     StepOut step = tracker.step(src, fi);
+    clk.m_step += since(tm0);
     if (step.prev_pts.empty()) {  // first keyframe (T:1715-1733)
       Keyframe kf(arena);
       kf.kf_id = (int)kfs.size();
@@ -910,7 +1061,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     }
     const std::vector<V2>& p_i = step.prev_pts;
     const std::vector<V2>& p_j = step.cur_pts;
+    const auto tm1 = Clock::now();
     auto rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk);  // T:1739
+    clk.m_ransac += since(tm1);
     int inliers = 0;
     double parallax = 0.0;
     if (rel) {
@@ -930,6 +1083,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       else if (inliers < cfg.kf_min_inliers) make_kf = true;
       else make_kf = parallax >= cfg.kf_parallax_px;
     }
+    const auto tm2 = Clock::now();
     if (make_kf) {
       join_lane();  // BA(k-1) refined the poses the triangulation below reads; edges stay in keyframe order
       Keyframe kf(arena);
@@ -1040,11 +1194,13 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         const int old_frame = old_kf.frame_idx;
         const sfmx_pyramid* cur_pyr = tracker.current();  // stays intact until the frame after next is loaded
         auto verify = [&, lc, old_frame, cur_pyr, pts0 = std::move(pts0)]() {
-          if (!old_pyr_c) check(cctx, sfmx_pyramid_create(cctx, w, h, tracker.levels_total(), &old_pyr_c), "pyramid_create");
-          src.load(cctx, old_frame, old_pyr_c);
+          sfmx_pyramid* opc = old_pyr_c;
+          if (lane_c) opc = lane_c->pooled()->pyramid(w, h, tracker.levels_total());  // lives with the pooled context
+          else if (!opc) { check(cctx, sfmx_pyramid_create(cctx, w, h, tracker.levels_total(), &old_pyr_c), "pyramid_create"); opc = old_pyr_c; }
+          src.load(cctx, old_frame, opc);
           std::vector<V2> fwd;
           std::vector<std::uint8_t> keep;
-          klt_pairs(cctx, lc, old_pyr_c, cur_pyr, pts0, fwd, keep, cclk);
+          klt_pairs(cctx, lc, opc, cur_pyr, pts0, fwd, keep, cclk);
           std::vector<V2> li, lj;
           for (size_t i = 0; i < pts0.size(); i++) {
             if (!keep[i]) continue;
@@ -1057,6 +1213,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         else { verify(); join_lane(); }
       }
     }
+    clk.m_kf += since(tm2);
     if (!make_kf) tracker.forget_corners(fi);  // only keyframe images are ever re-detected (loop closure)
     emit(fi);
   }
@@ -1150,6 +1307,7 @@ struct sfmx_pipeline_stats {
   unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks, shi_calls, shi_memo_hits, shi_prefetched;
   double sec_shi_wait, sec_setup, sec_wall;
   double sec_pf_busy, sec_pf_gpu, sec_pf_replay, sec_lane_b_busy, sec_lane_c_busy, sec_join_wait, sec_ba_gather;
+  double sec_m_step, sec_m_ransac, sec_m_kf;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -1195,7 +1353,8 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
                                    c.total, c.klt, c.shi, c.ransac, c.ba, c.upload, c.host, c.shi_gpu, c.shi_replay, c.desc, c.bookkeeping, c.r_pre, c.r_gpu, c.r_verify, c.r_decomp, c.tri_iter, c.tri_solve, c.tri_insert,
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
                                    c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait, c.setup, wall,
-                                   c.pf_busy, c.pf_gpu, c.pf_replay, c.lane_b_busy, c.lane_c_busy, c.join_wait, c.ba_gather};
+                                   c.pf_busy, c.pf_gpu, c.pf_replay, c.lane_b_busy, c.lane_c_busy, c.join_wait, c.ba_gather,
+                                   c.m_step, c.m_ransac, c.m_kf};
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {
@@ -1212,6 +1371,9 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     return SFMX_ERR_INVALID;
   }
 }
+
+// frees the helper contexts kept for reuse by later sfmx_pipeline_run calls
+void sfmx_host_release_contexts() { sfmx_host::ContextPool::instance().clear(); }
 
 // host-side math self-checks used by the CPU test-suite (no device involved)
 // Iteration order of an unordered_map<int,int> filled (and partly erased) with `keys`: default allocator vs the bump

@@ -72,22 +72,64 @@ struct StageClock {
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
   double shi_wait = 0, setup = 0;
   double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_b_busy = 0, lane_c_busy = 0, join_wait = 0, ba_gather = 0;
+  double m_step = 0, m_ransac = 0, m_kf = 0;  // main-lane wall time: tracker.step / frame->frame RANSAC / keyframe block
 };
 
 // shi_tomasi (T:237-302) on one context: device score + certain-outcome fixpoint (sfmx_shi_tomasi_candidates_pruned),
 // then the reference's sort + greedy min-distance pick on the few surviving candidates (tie order via the
 // introsort replay when needed).  One detector per context / per thread.
+// Helper contexts (corner prefetch workers, lanes B/C) are recycled across pipeline runs of one process: creating and
+// destroying a context -- streams, hipMalloc/hipHostMalloc'ed slabs that grow on first use, captured graphs -- costs
+// several milliseconds per run, more than a tenth of a 47-frame pass.  Entries are leaked at process exit on purpose
+// (no HIP calls from static destructors); sfmx_host_release_contexts() frees them explicitly.
+struct PooledCtx {
+  sfmx_ctx* ctx = nullptr;
+  int device = 0, priority = 0;
+  sfmx_pyramid* pyr = nullptr;  // one scratch pyramid that lives with the context
+  int pw = 0, ph = 0, pl = 0;
+  sfmx_pyramid* pyramid(int w, int h, int levels);  // (re)created when the geometry changes
+};
+class ContextPool {
+ public:
+  static ContextPool& instance();
+  PooledCtx* acquire(int device, int priority);
+  void release(PooledCtx* pc);  // synchronises the context; the caller's threads must have stopped using it
+  void clear();
+
+ private:
+  std::mutex mu_;
+  std::vector<PooledCtx*> free_;
+};
+
+// A detection whose tie order still has to be resolved on the host (no device access needed any more): the survivors
+// of the device fixpoint plus a private copy of the sort keys of ALL candidates.
+struct CornerTies {
+  int w = 0, h = 0, min_dist = 0, max_corners = 0, n_total = 0;
+  std::vector<std::uint32_t> xy;       // survivors: x | y<<16 (| certain-accept flag in bit 31)
+  std::vector<double> s;               // survivors: score
+  std::vector<std::int32_t> full;      // survivors: index in the full candidate list
+  std::vector<SortKey> keys;           // all candidates, row-major (the reference's push order, T:282-284)
+};
+
 class CornerDetector {
  public:
   CornerDetector(sfmx_ctx* ctx, StageClock* clk) : ctx_(ctx), clk_(clk) {}
   std::vector<V2> detect(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist);
+  // Two-phase form used by the prefetcher.  detect_device: device score + fixpoint and the tie-free host walk;
+  // returns true when `out` is final, false when `ties` was filled and resolve_ties() has to finish the job.
+  bool detect_device(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist, std::vector<V2>& out, CornerTies& ties);
+  // pure host code (any thread, no context): introsort replay + greedy pick.  false = replay declined (the caller
+  // falls back to detect(), i.e. the reference's own sort call on the full list).
+  static bool resolve_ties(CornerTies& ties, std::vector<V2>& out, StageClock* clk);
 
  private:
+  std::vector<V2> detect_full_sort(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist);
   sfmx_ctx* ctx_;
   StageClock* clk_;
   std::vector<std::uint32_t> cand_xy_;
   std::vector<double> cand_s_;
   std::vector<std::int32_t> cand_full_;
+  CornerTies ties_;  // scratch of the synchronous detect()
 };
 
 // Corner detection of frame f+1 depends only on image f+1, so it is computed ahead of time by a worker thread
@@ -108,16 +150,25 @@ class CornerPrefetcher {
   std::uint64_t replays();                          // tie-order replays over all workers (call after the run)
 
  private:
-  // one worker = one thread + one context + one detector; frames are handed out from a shared queue
+  // one worker = a device thread (own context + detector) and a resolver thread (host-only tie resolution of the
+  // previous image while the device thread is already on the next one); frames come from a shared queue
   struct Worker {
-    sfmx_ctx* ctx = nullptr;
-    sfmx_pyramid* pyr = nullptr;
+    PooledCtx* pc = nullptr;
+    sfmx_ctx* ctx = nullptr;      // = pc->ctx
+    sfmx_pyramid* pyr = nullptr;  // = pc's scratch pyramid
     std::unique_ptr<CornerDetector> det;
-    StageClock clock;
-    double busy = 0;
-    std::thread th;
+    StageClock clock, clock_resolver;
+    double busy = 0, busy_resolver = 0;
+    std::thread th, th_resolver;
+    // tie hand-over between the two threads (all guarded by the prefetcher's mutex)
+    CornerTies ties[2];
+    std::vector<CornerTies*> free_ties;
+    std::deque<std::pair<int, CornerTies*>> ties_queue;
+    std::condition_variable cv_ties;
   };
   void run(Worker& w);
+  void run_resolver(Worker& w);
+  void publish(int frame, std::vector<V2>&& seq, bool failed);
   void shutdown();
   struct Slot { bool done = false, failed = false; std::vector<V2> corners; };
   FrameSource& src_;
@@ -168,6 +219,7 @@ class GpuTracker {
   sfmx_pyramid* cur_ = nullptr;
   bool have_prev_ = false;
   std::vector<Track> tracks_;
+  std::vector<int> grid_head_, grid_next_;  // scratch of the replenish distance filter
   int next_id_ = 0;
   StageClock* clk_;
   CornerDetector det_;
@@ -260,11 +312,12 @@ class GpuBundleAdjuster {
 // Tasks run in submission order; wait() blocks until the lane is idle and rethrows the first task exception.
 class AsyncLane {
  public:
-  explicit AsyncLane(int device);
+  AsyncLane(int device, int priority);  // priority: sfmx_ctx_create_prio
   ~AsyncLane();
   AsyncLane(const AsyncLane&) = delete;
   AsyncLane& operator=(const AsyncLane&) = delete;
   sfmx_ctx* ctx() const { return ctx_; }
+  PooledCtx* pooled() const { return pc_; }
   void submit(std::function<void()> task);
   void wait();
   double busy_seconds() const { return busy_seconds_; }  // time spent inside tasks (read while idle)
@@ -272,6 +325,7 @@ class AsyncLane {
  private:
   void run();
   double busy_seconds_ = 0;
+  PooledCtx* pc_ = nullptr;
   sfmx_ctx* ctx_ = nullptr;
   std::thread th_;
   std::mutex mu_;
