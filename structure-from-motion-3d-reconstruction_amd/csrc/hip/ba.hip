@@ -216,15 +216,24 @@ __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const d
   C[(size_t)p * CS + e] = v;
 }
 
-// Ordered column sums: one lane per element of S / b walks the contribution rows in point order.
-// Loads of neighbouring lanes are contiguous (coalesced) and independent of the add chain, so they
-// are issued BA_AHEAD points ahead; the dependent FP64 adds are the only serial part.
-#define BA_AHEAD 32
-__global__ __launch_bounds__(64) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
-                                                  double* __restrict__ b) {
-  const int D = 6 * W, CS = ba_row_stride(W);
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= D * D + D) return;
+// Ordered column sums.  The add chain of one element of S / b over the points is strictly serial (reference order),
+// but its operands are not: a workgroup owns BAR_COLS neighbouring elements, all 256 threads stream the next tile of
+// BAR_TP contribution rows into LDS (32 independent loads per thread in flight, 128-byte segments) while 16 lanes of
+// wave 0 run the add chains over the previous tile.  Missing second addends are +0.0 (identity, see above); "b -= G*bp"
+// is evaluated as b += (-(G*bp)), which is the same IEEE operation.
+#define BAR_COLS 16
+#define BAR_TP 256
+#define BAR_Q (256 / BAR_COLS)        // point phases per tile pass
+#define BAR_K (BAR_TP / BAR_Q)        // rows per thread and tile
+__global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
+                                                   double* __restrict__ b) {
+  __shared__ double sv[2][BAR_TP][BAR_COLS];
+  __shared__ double su[2][BAR_TP][BAR_COLS];
+  const int D = 6 * W, CS = ba_row_stride(W), NE = D * D + D;
+  const int tid = threadIdx.x, col = tid % BAR_COLS, q = tid / BAR_COLS;
+  const int e_raw = blockIdx.x * BAR_COLS + col;
+  const bool valid = e_raw < NE;
+  const int e = valid ? e_raw : NE - 1;
   const bool is_b = e >= D * D;
   const int i = is_b ? e - D * D : e / D;
   const int j = is_b ? 0 : e % D;
@@ -233,33 +242,71 @@ __global__ __launch_bounds__(64) void k_ba_reduce(int W, int P, const double* __
   const int o1 = is_b ? (D * D + 36 * W + i) : (D * D + (i / 6) * 36 + (i % 6) * 6 + (j % 6));
   const int o2 = is_b ? (D * D + 36 * W + D + i) : e;
   const bool two = is_b || diag_blk;
-  double acc = 0.0;
-  for (int p0 = 0; p0 < P; p0 += BA_AHEAD) {
-    double u[BA_AHEAD], v[BA_AHEAD];
+  const bool any_two = __any(two);  // uniform over the block: every wave holds the same BAR_COLS columns
+  const int ntiles = (P + BAR_TP - 1) / BAR_TP;
+  double rv[BAR_K], ru[BAR_K];
+  auto load_tile = [&](int t) {
 #pragma unroll
-    for (int k = 0; k < BA_AHEAD; k++) {
-      const int p = min(p0 + k, P - 1);
+    for (int k = 0; k < BAR_K; k++) {
+      const int p = min(t * BAR_TP + k * BAR_Q + q, P - 1);
       const double* row = C + (size_t)p * CS;
-      v[k] = row[o2];
-      u[k] = two ? row[o1] : 0.0;
+      const double v = row[o2];
+      rv[k] = is_b ? -v : v;
+      ru[k] = two ? row[o1] : 0.0;
     }
+  };
+  auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int k = 0; k < BA_AHEAD; k++) {
-      if (p0 + k < P) {
-        if (is_b) { acc += u[k]; acc -= v[k]; }          // b += bx ; b -= G*bp
-        else { if (diag_blk) acc += u[k]; acc += v[k]; }  // S += Hxx ; S += G_a Hxp_b^T  (reference ADDS, Q6)
+    for (int k = 0; k < BAR_K; k++) {
+      sv[buf][k * BAR_Q + q][col] = rv[k];
+      su[buf][k * BAR_Q + q][col] = ru[k];
+    }
+  };
+  double acc = 0.0;
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; t++) {
+    if (t + 1 < ntiles) load_tile(t + 1);
+    if (tid < BAR_COLS) {
+      const int buf = t & 1, cnt = min(BAR_TP, P - t * BAR_TP);
+      int pp = 0;
+      if (any_two) {
+        for (; pp + 8 <= cnt; pp += 8) {
+          double u[8], v[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) { u[k] = su[buf][pp + k][col]; v[k] = sv[buf][pp + k][col]; }
+#pragma unroll
+          for (int k = 0; k < 8; k++) { acc += u[k]; acc += v[k]; }  // S += Hxx ; S += G_a Hxp_b^T (reference ADDS, Q6) | b += bx ; b -= G*bp
+        }
+        for (; pp < cnt; pp++) { acc += su[buf][pp][col]; acc += sv[buf][pp][col]; }
+      } else {
+        for (; pp + 16 <= cnt; pp += 16) {
+          double v[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) v[k] = sv[buf][pp + k][col];
+#pragma unroll
+          for (int k = 0; k < 16; k++) acc += v[k];
+        }
+        for (; pp < cnt; pp++) acc += sv[buf][pp][col];
       }
     }
+    if (t + 1 < ntiles) store_tile((t + 1) & 1);
+    __syncthreads();
   }
-  if (is_b) {
-    if (damp && i < 6) acc = 0.0;  // T:1070
-    b[i] = acc;
-  } else {
-    if (damp && i == j) {
-      acc += lambda;          // T:1064
-      if (i < 6) acc += 1e9;  // T:1069
+  if (tid < BAR_COLS && valid) {
+    if (is_b) {
+      if (damp && i < 6) acc = 0.0;  // T:1070
+      b[i] = acc;
+    } else {
+      if (damp && i == j) {
+        acc += lambda;          // T:1064
+        if (i < 6) acc += 1e9;  // T:1069
+      }
+      S[(size_t)i * D + j] = acc;
     }
-    S[(size_t)i * D + j] = acc;
   }
 }
 
@@ -278,6 +325,27 @@ __global__ __launch_bounds__(64) void k_ba_reduce(int W, int P, const double* __
 //   back-substitution: products A(i,j)*x_j are formed by all rows as soon as x_j exists, so only the
 //             reference's ascending-j subtraction chain of the current row is serial.
 #define SOLVE_WAVE_MAX_N 64
+// wave-wide maximum of non-NaN doubles by DPP (no LDS round trips): after the row steps every lane of a 16-lane row
+// holds the row maximum; row_bcast15 / row_bcast31 carry it across rows; lane 63 ends up with the wave maximum.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max_step(double m) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(m), __double2loint(m), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(m), __double2hiint(m), CTRL, ROW_MASK, 0xF, false);
+  const double t = __hiloint2double(hi, lo);
+  return t > m ? t : m;
+}
+__device__ __forceinline__ double wave_max_f64(double m) {
+  m = dpp_max_step<0xB1, 0xF>(m);   // quad_perm [1,0,3,2]
+  m = dpp_max_step<0x4E, 0xF>(m);   // quad_perm [2,3,0,1]
+  m = dpp_max_step<0x141, 0xF>(m);  // row_half_mirror
+  m = dpp_max_step<0x140, 0xF>(m);  // row_mirror
+  m = dpp_max_step<0x142, 0xA>(m);  // row_bcast15 into rows 1 and 3
+  m = dpp_max_step<0x143, 0xC>(m);  // row_bcast31 into rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(m), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(m), 63);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(64) void k_solve_wave(const double* __restrict__ Ain, const double* __restrict__ bin, int n,
                                                    double* __restrict__ x, int* __restrict__ status) {
   __shared__ double A[SOLVE_WAVE_MAX_N * (SOLVE_WAVE_MAX_N + 1)];
@@ -293,11 +361,7 @@ __global__ __launch_bounds__(64) void k_solve_wave(const double* __restrict__ Ai
     const bool mine = lane >= k && lane < n;
     const double v = mine ? fabs(A[lane * ld + k]) : -1.0;
     const double akk0 = fabs(A[k * ld + k]);
-    double m = (v == v) ? v : -1.0;  // NaN below the diagonal never wins `v > best`
-    for (int o = 32; o > 0; o >>= 1) {
-      const double t = __shfl_xor(m, o, 64);
-      m = t > m ? t : m;
-    }
+    const double m = wave_max_f64((v == v) ? v : -1.0);  // NaN below the diagonal never wins `v > best`
     int piv = k;
     double best = akk0;
     if (akk0 == akk0) {  // a NaN on the diagonal stays the pivot: `v > NaN` is never true
@@ -309,37 +373,50 @@ __global__ __launch_bounds__(64) void k_solve_wave(const double* __restrict__ Ai
       if (lane == 0) status[0] = 1;
       return;
     }
-    // ---- row swap on columns k..n-1 (lanes as columns), b too
+    // ---- row swap on columns k..n-1 (lanes as columns) fused with the normalisation of the new row k:
+    // A[k][j] = A[piv][j] / A[piv][k], A[piv][j] = old A[k][j]; b likewise.  Every lane reads its operands before
+    // it stores (the stores may alias the loads, so the compiler keeps that order), and the wave runs in lockstep.
     const int j = k + lane;
-    if (piv != k) {
-      if (j < n) {
-        const double t = A[k * ld + j];
-        A[k * ld + j] = A[piv * ld + j];
-        A[piv * ld + j] = t;
+    const double akk = A[piv * ld + k];
+    {
+      // b rides along as "column n" (lane n-k), so that its division shares the instruction with the row's
+      const bool b_lane = j == n;
+      double* pk = b_lane ? &bb[k] : &A[k * ld + j];
+      double* pp = b_lane ? &bb[piv] : &A[piv * ld + j];
+      if (j <= n) {
+        const double top = *pk, low = *pp;
+        *pk = low / akk;
+        if (piv != k) *pp = top;
       }
-      if (lane == 0) { const double t = bb[k]; bb[k] = bb[piv]; bb[piv] = t; }
+      if (n - k > 63 && lane == 0) {  // n == 64, k == 0: there is no lane 64
+        const double bk = bb[k], bp = bb[piv];
+        bb[k] = bp / akk;
+        if (piv != k) bb[piv] = bk;
+      }
     }
     __syncthreads();
-    // ---- normalise row k
-    const double akk = A[k * ld + k];
-    __syncthreads();
-    if (j < n) A[k * ld + j] = A[k * ld + j] / akk;
-    if (lane == 0) bb[k] = bb[k] / akk;
-    __syncthreads();
-    // ---- eliminate rows below (dense.hpp:78-83)
-    if (lane > k && lane < n) {
-      double* row = A + lane * ld;
-      const double* rk = A + k * ld;
-      const double f = row[k];
-      if (!(fabs(f) < 1e-18)) {
-        int c = k;
-        for (; c + 4 <= n; c += 4) {
-          const double r0 = rk[c], r1 = rk[c + 1], r2 = rk[c + 2], r3 = rk[c + 3];
-          const double a0 = row[c], a1 = row[c + 1], a2 = row[c + 2], a3 = row[c + 3];
-          row[c] = a0 - f * r0; row[c + 1] = a1 - f * r1; row[c + 2] = a2 - f * r2; row[c + 3] = a3 - f * r3;
+    // ---- eliminate rows below (dense.hpp:78-83): row r = k+1+(lane / L) is shared by L = 2^s lanes, each taking
+    // every L-th column -- the element updates a_rc -= f_r * a_kc are independent of each other.  All lanes of a row
+    // read the multiplier f_r = a_rk in the same instruction, before the lane owning column k overwrites it.
+    const int rows = n - k - 1;
+    if (rows > 0) {
+      int L = 1;
+      while (2 * L * rows <= 64) L *= 2;
+      const int r = k + 1 + lane / L, part = lane % L;
+      if (lane / L < rows) {
+        double* row = A + r * ld;
+        const double* rk = A + k * ld;
+        const double f = row[k];
+        if (!(fabs(f) < 1e-18)) {
+          int c = k + part;
+          for (; c + 3 * L < n; c += 4 * L) {
+            const double r0 = rk[c], r1 = rk[c + L], r2 = rk[c + 2 * L], r3 = rk[c + 3 * L];
+            const double a0 = row[c], a1 = row[c + L], a2 = row[c + 2 * L], a3 = row[c + 3 * L];
+            row[c] = a0 - f * r0; row[c + L] = a1 - f * r1; row[c + 2 * L] = a2 - f * r2; row[c + 3 * L] = a3 - f * r3;
+          }
+          for (; c < n; c += L) row[c] = row[c] - f * rk[c];
+          if (part == 0) bb[r] = bb[r] - f * bb[k];
         }
-        for (; c < n; c++) row[c] = row[c] - f * rk[c];
-        bb[lane] = bb[lane] - f * bb[k];
       }
     }
     __syncthreads();
@@ -505,7 +582,7 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
                                                     huber, q->rec, q->slot_of);
   const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
   k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib);
-  k_ba_reduce<<<(D * D + D + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b);
+  k_ba_reduce<<<(D * D + D + BAR_COLS - 1) / BAR_COLS, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;

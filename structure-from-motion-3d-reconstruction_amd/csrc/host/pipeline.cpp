@@ -997,25 +997,43 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   MapState& map = out.map;
   std::vector<PGEdge>& edges = out.edges;
   // wait for lane B and fold its results in, in submission order (odometry edge of keyframe k, then BA(k))
-  auto join_lane = [&]() {
+  // Joining is split so that the wait for BA(k) can be pushed as late as the data dependence allows:
+  //   join_c: lane C is done -> append its edge(s); returns true if the loop closure of keyframe k was accepted
+  //   join_b: lane B is done -> write BA(k)'s poses back
+  //   finish_loop: loop edge + pose graph + second BA (T:1859-1863), needs both
+  std::optional<PendingLoop> accepted_loop;
+  auto join_c = [&]() -> bool {
     const auto tj = Clock::now();
-    if (lane) lane->wait();
     if (lane_c) lane_c->wait();
     clk.join_wait += since(tj);
     for (PendingEdge& pe : pending_edges)
       if (pe.rel) edges.push_back(PGEdge{pe.i, pe.j, pe.rel->R_ji, pe.rel->t_ji, (int)pe.rel->inliers.size(), false});
     pending_edges.clear();
-    GpuBundleAdjuster::apply(pending_ba, kfs);
-    pending_ba = BaJob{};
-    if (pending_loop.active) {  // verdict of the loop-closure verification of the last keyframe (T:1858-1864)
+    if (pending_loop.active) {  // verdict of the loop-closure verification of the last keyframe (T:1858)
       const PendingLoop pl = pending_loop;
       pending_loop = PendingLoop{};
-      if (pl.rel && (int)pl.rel->inliers.size() >= 100) {
-        edges.push_back(PGEdge{pl.old_kf, pl.new_kf, pl.rel->R_ji, pl.rel->t_ji, (int)pl.rel->inliers.size(), true});
-        (void)posegraph_optimize_centers(ctx, kfs, edges);
-        ba.run(K, kfs, map, cfg.ba);  // the lanes are idle here: lane B's context is used from this thread
-      }
+      if (pl.rel && (int)pl.rel->inliers.size() >= 100) accepted_loop = pl;
     }
+    return accepted_loop.has_value();
+  };
+  auto join_b = [&]() {
+    const auto tj = Clock::now();
+    if (lane) lane->wait();
+    clk.join_wait += since(tj);
+    GpuBundleAdjuster::apply(pending_ba, kfs);
+    pending_ba = BaJob{};
+  };
+  auto finish_loop = [&]() {
+    const PendingLoop pl = *accepted_loop;
+    accepted_loop.reset();
+    edges.push_back(PGEdge{pl.old_kf, pl.new_kf, pl.rel->R_ji, pl.rel->t_ji, (int)pl.rel->inliers.size(), true});
+    (void)posegraph_optimize_centers(ctx, kfs, edges);
+    ba.run(K, kfs, map, cfg.ba);  // the lanes are idle here: lane B's context is used from this thread
+  };
+  auto join_lane = [&]() {
+    const bool looped = join_c();
+    join_b();
+    if (looped) finish_loop();
   };
   std::vector<std::vector<float>> kf_desc;
   Arena* arena = out.arena.get();
@@ -1085,7 +1103,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     }
     const auto tm2 = Clock::now();
     if (make_kf) {
-      join_lane();  // BA(k-1) refined the poses the triangulation below reads; edges stay in keyframe order
+      // Edges stay in keyframe order (lane C first).  BA(k-1) refined the poses the triangulation below reads, but
+      // nothing before it does: unless a loop closure has to be finished first, lane B is joined as late as that.
+      const bool looped = join_c();
+      if (looped) { join_b(); finish_loop(); }
       Keyframe kf(arena);
       kf.kf_id = (int)kfs.size();
       kf.frame_idx = fi;
@@ -1123,6 +1144,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           else task();
         }
       }
+      if (!looped) join_b();
       if (kfs.size() >= 1) {  // triangulate new points (T:1801-1813)
         const auto th0 = Clock::now();
         // The DLT solves (libm Jacobi) are independent: gather the jobs in the reference's iteration
