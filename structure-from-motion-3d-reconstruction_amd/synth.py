@@ -20,16 +20,23 @@ import numpy as np
 K_TEMPLE = np.array([[1520.4, 0.0, 302.32], [0.0, 1525.9, 246.87], [0.0, 0.0, 1.0]])
 
 
-def make_scene(n_blobs: int = 20000, seed: int = 7):
+def make_scene(n_blobs: int = 20000, seed: int = 7, shell_scale: float = 1.0, coarse_frac: float = 0.0):
+    """shell_scale > 1 inflates the shell (x3.5 fills a 640x480 frame with texture: the 5k-track config C3);
+    coarse_frac of the blobs are drawn 5x wider so that the upper pyramid levels keep structure when the fine blobs
+    are dense enough to merge there."""
     rng = np.random.default_rng(seed)
     d = rng.normal(size=(n_blobs, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     # bumpy, non-planar shell: radius depends smoothly on direction plus jitter
     bump = 0.085 + 0.012 * np.sin(7.0 * d[:, 0]) * np.cos(5.0 * d[:, 1]) + 0.003 * rng.normal(size=n_blobs)
-    r = np.clip(bump, 0.07, 0.10)
+    r = np.clip(bump, 0.07, 0.10) * shell_scale
     pts = d * r[:, None]
     sigma = rng.uniform(1.2, 2.2, size=n_blobs)
     amp = rng.uniform(60.0, 210.0, size=n_blobs)
+    if coarse_frac > 0.0:  # drawn after everything else: the default scene (coarse_frac = 0) is unchanged
+        coarse = rng.random(n_blobs) < coarse_frac
+        sigma = np.where(coarse, sigma * 5.0, sigma)
+        amp = np.where(coarse, amp * 0.5, amp)
     return dict(pts=pts, normals=d, sigma=sigma, amp=amp)
 
 
@@ -57,22 +64,25 @@ def render(scene, R, t, K, w: int, h: int, rng: np.random.Generator | None, back
     z = Xc[:, 2]
     u = K[0, 0] * Xc[:, 0] / z + K[0, 2]
     v = K[1, 1] * Xc[:, 1] / z + K[1, 2]
-    rad = 6
-    ok = facing & (z > 1e-3) & (u > -rad) & (u < w + rad) & (v > -rad) & (v < h + rad)
-    u, v = u[ok], v[ok]
-    sig = scene["sigma"][ok] * scale
-    amp = scene["amp"][ok]
     img = np.full((h, w), background, np.float64)
-    u0 = np.floor(u).astype(np.int64)
-    v0 = np.floor(v).astype(np.int64)
-    offs = np.arange(-rad, rad + 1)
-    dx, dy = np.meshgrid(offs, offs)
-    dx, dy = dx.ravel(), dy.ravel()
-    X = u0[:, None] + dx[None, :]
-    Y = v0[:, None] + dy[None, :]
-    val = amp[:, None] * np.exp(-((X - u[:, None]) ** 2 + (Y - v[:, None]) ** 2) / (2.0 * sig[:, None] ** 2))
-    inside = (X >= 0) & (X < w) & (Y >= 0) & (Y < h)
-    np.add.at(img, (Y[inside], X[inside]), val[inside])
+    sig_all = scene["sigma"] * scale
+    for rad, pick in ((6, sig_all <= 3.0 * scale), (30, sig_all > 3.0 * scale)):  # fine blobs, then the wide ones
+        ok = pick & facing & (z > 1e-3) & (u > -rad) & (u < w + rad) & (v > -rad) & (v < h + rad)
+        if not ok.any():
+            continue
+        uu, vv = u[ok], v[ok]
+        sig = sig_all[ok]
+        amp = scene["amp"][ok]
+        u0 = np.floor(uu).astype(np.int64)
+        v0 = np.floor(vv).astype(np.int64)
+        offs = np.arange(-rad, rad + 1)
+        dx, dy = np.meshgrid(offs, offs)
+        dx, dy = dx.ravel(), dy.ravel()
+        X = u0[:, None] + dx[None, :]
+        Y = v0[:, None] + dy[None, :]
+        val = amp[:, None] * np.exp(-((X - uu[:, None]) ** 2 + (Y - vv[:, None]) ** 2) / (2.0 * sig[:, None] ** 2))
+        inside = (X >= 0) & (X < w) & (Y >= 0) & (Y < h)
+        np.add.at(img, (Y[inside], X[inside]), val[inside])
     if rng is not None:
         img += rng.normal(size=img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
@@ -80,14 +90,14 @@ def render(scene, R, t, K, w: int, h: int, rng: np.random.Generator | None, back
 
 def make_sequence(n_frames: int, w: int = 640, h: int = 480, deg_per_frame: float = 0.3, n_blobs: int = 20000,
                   seed: int = 7, noise: bool = True, K: np.ndarray | None = None, dist: float = 0.65,
-                  start_deg: float = 0.0, angles=None):
+                  start_deg: float = 0.0, angles=None, shell_scale: float = 1.0, coarse_frac: float = 0.0):
     """Returns dict(images [F,h,w] u8, K, R [F,3,3], t [F,3], names, lat, lon).
     angles (optional): explicit ring angle in degrees per frame (e.g. out-and-back paths that revisit a view)."""
     if K is None:
         K = K_TEMPLE.copy()
         K[0, :] *= w / 640.0
         K[1, :] *= h / 480.0
-    scene = make_scene(n_blobs, seed)
+    scene = make_scene(n_blobs, seed, shell_scale, coarse_frac)
     rng = np.random.default_rng(seed + 1000) if noise else None
     imgs = np.zeros((n_frames, h, w), np.uint8)
     Rs = np.zeros((n_frames, 3, 3))
