@@ -123,10 +123,9 @@ def write_pgm(path: str, img: np.ndarray) -> None:
         f.write(np.ascontiguousarray(img, np.uint8).tobytes())
 
 
-def write_dataset(root: str, seq) -> None:
-    """Write the reference CLI's input layout under ``root``."""
+def write_par_ang(root: str, seq) -> None:
+    """<root>/templeRing/templeR_par.txt and templeR_ang.txt (the ground truth the evaluators read)."""
     os.makedirs(os.path.join(root, "templeRing"), exist_ok=True)
-    os.makedirs(os.path.join(root, "templeRing_pgm"), exist_ok=True)
     n = len(seq["names"])
     with open(os.path.join(root, "templeRing", "templeR_par.txt"), "w") as f:
         f.write(f"{n}\n")
@@ -136,6 +135,12 @@ def write_dataset(root: str, seq) -> None:
     with open(os.path.join(root, "templeRing", "templeR_ang.txt"), "w") as f:
         for i in range(n):
             f.write(f"{float(seq['lat'][i])!r} {float(seq['lon'][i])!r} {seq['names'][i]}\n")
-    for i in range(n):
+
+
+def write_dataset(root: str, seq) -> None:
+    """Write the reference CLI's input layout under ``root``."""
+    write_par_ang(root, seq)
+    os.makedirs(os.path.join(root, "templeRing_pgm"), exist_ok=True)
+    for i in range(len(seq["names"])):
         stem = os.path.splitext(seq["names"][i])[0]
         write_pgm(os.path.join(root, "templeRing_pgm", stem + ".pgm"), seq["images"][i])

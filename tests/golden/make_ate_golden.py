@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Fixtures for the ATE evaluator (tests/test_tools.py): inputs (a par file, keyframe CSVs) and the stdout / stderr /
+exit code the REAL reference tool gives on them.  Needs oracle/_ref/ate_keyframes_ref (make -C oracle ref), i.e. it
+only runs where /root/reference exists; the resulting tests/golden/ate_keyframes.json is committed."""
+import importlib, json, os, subprocess, sys, tempfile
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H
+synth = importlib.import_module(H.PKG_NAME + ".synth")
+REF = os.path.join(ROOT, "oracle", "_ref", "ate_keyframes_ref")
+
+
+def par_text(seq):
+    lines = [str(len(seq["names"]))]
+    for i, n in enumerate(seq["names"]):
+        vals = list(seq["K"].ravel()) + list(seq["R"][i].ravel()) + list(seq["t"][i].ravel())
+        lines.append(n + " " + " ".join(repr(float(v)) for v in vals))
+    return "\n".join(lines) + "\n"
+
+
+def main():
+    rng = np.random.default_rng(11)
+    seq = synth.make_sequence(16, 64, 48, 7.0, n_blobs=10, seed=3, noise=False)  # only the poses matter
+    C = np.array([-seq["R"][i].T @ seq["t"][i] for i in range(16)])
+    # an "estimated" trajectory: ground truth under an unknown similarity + noise (monocular gauge), 6 significant digits
+    th = 0.7
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    est = 3.7 * (C @ Rz.T) + np.array([0.4, -1.2, 2.5]) + rng.normal(size=C.shape) * 0.02
+    def csv(points, names, header="kf_id,frame_idx,image,x,y,z,lat,lon", extra_rows=()):
+        rows = [header]
+        for k, (p, n) in enumerate(zip(points, names)):
+            rows.append(f"{k},{k},{n},{p[0]:.6g},{p[1]:.6g},{p[2]:.6g},0,{7.0 * k:.6g}")
+        rows.extend(extra_rows)
+        return "\n".join(rows) + "\n"
+    files = {
+        "par.txt": par_text(seq),
+        "kf.csv": csv(est, seq["names"]),
+        "kf_exact.csv": csv(2.0 * C, seq["names"]),                                    # zero residual up to rounding
+        "kf_mirror.csv": csv(est * np.array([1, 1, -1.0]), seq["names"]),               # reflection branch (D(2,2) = -1)
+        "kf_line.csv": csv(np.stack([np.linspace(0, 1, 16), np.zeros(16), np.zeros(16)], 1), seq["names"]),  # rank-1 covariance
+        "kf_quoted.csv": csv(est, ['"' + n + '"' for n in seq["names"]], extra_rows=["bad,row", "9,9,x.png,a,b,c,0,0", ""]),
+        "kf_nocol.csv": csv(est, seq["names"], header="kf_id,frame_idx,image,px,y,z,lat,lon"),
+        "kf_unknown.csv": csv(est, ["nope.png"] + list(seq["names"][1:])),
+    }
+    cases = [
+        ["--par", "par.txt", "--keyframes", "kf.csv"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--count", "16"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--start", "3", "--count", "9", "--se3"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--count", "16", "--se3", "--sim3"],
+        ["--par", "par.txt", "--keyframes", "kf_exact.csv", "--count", "12"],
+        ["--par", "par.txt", "--keyframes", "kf_mirror.csv", "--count", "16"],
+        ["--par", "par.txt", "--keyframes", "kf_line.csv", "--count", "8"],
+        ["--par", "par.txt", "--keyframes", "kf_quoted.csv", "--count", "16"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--count", "2"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--count", "abc", "--start", "1x"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--start", "10", "--count", "9"],   # range error
+        ["--par", "par.txt", "--keyframes", "kf_nocol.csv"],                              # missing column
+        ["--par", "par.txt", "--keyframes", "kf_unknown.csv"],                            # name not in par
+        ["--par", "missing.txt", "--keyframes", "kf.csv"],                                # unreadable par
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--count", "1"],                    # usage
+        ["--keyframes", "kf.csv"],                                                        # usage
+    ]
+    out = {"files": files, "cases": []}
+    with tempfile.TemporaryDirectory() as d:
+        for n, txt in files.items():
+            open(os.path.join(d, n), "w").write(txt)
+        for args in cases:
+            r = subprocess.run([REF] + args, cwd=d, capture_output=True, text=True)
+            out["cases"].append({"args": args, "rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr})
+            print(args, "->", r.returncode, r.stdout.count("\n"), "lines")
+    json.dump(out, open(os.path.join(HERE, "ate_keyframes.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
