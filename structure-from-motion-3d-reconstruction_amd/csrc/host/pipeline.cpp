@@ -34,27 +34,40 @@ void MemoryFrames::load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) {
 }
 
 // ------------------------------------------------------------------------------------------ tracker
-GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk)
-    : ctx_(ctx), cfg_(cfg), w_(w), h_(h), clk_(clk), det_(ctx, clk) {
+GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk, int ring, std::function<void(int)> before_load)
+    : ctx_(ctx), cfg_(cfg), w_(w), h_(h), before_load_(std::move(before_load)), clk_(clk), det_(ctx, clk) {
   levels_total_ = std::max(cfg.pyr_levels, extra_levels);
-  check(ctx_, sfmx_pyramid_create(ctx_, w, h, levels_total_, &prev_), "pyramid_create");
-  check(ctx_, sfmx_pyramid_create(ctx_, w, h, levels_total_, &cur_), "pyramid_create");
+  try {
+    for (int i = 0; i < std::max(2, ring); i++) {
+      sfmx_pyramid* p = nullptr;
+      check(ctx_, sfmx_pyramid_create(ctx_, w, h, levels_total_, &p), "pyramid_create");
+      ring_.push_back(p);
+    }
+  } catch (...) {
+    for (sfmx_pyramid* p : ring_) sfmx_pyramid_destroy(ctx_, p);
+    throw;
+  }
 }
 GpuTracker::~GpuTracker() {
-  sfmx_pyramid_destroy(ctx_, prev_);
-  sfmx_pyramid_destroy(ctx_, cur_);
+  for (sfmx_pyramid* p : ring_) sfmx_pyramid_destroy(ctx_, p);
+}
+
+std::shared_ptr<const CornerMemo> GpuTracker::take_memo(int frame_key) {
+  auto it = corner_cache_.find(frame_key);
+  if (it == corner_cache_.end()) return nullptr;
+  auto m = std::make_shared<const CornerMemo>(std::move(it->second));
+  corner_cache_.erase(it);
+  return m;
 }
 
 std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist, int frame_key) {
   const auto t0 = Clock::now();
   if (clk_) clk_->shi_calls++;
-  auto prefix = [&](const std::vector<V2>& cc) { return std::vector<V2>(cc.begin(), cc.begin() + (long)std::min((size_t)std::max(max_corners, 0), cc.size())); };
   if (frame_key >= 0 && max_corners >= 1) {
     auto it = corner_cache_.find(frame_key);
-    if (it != corner_cache_.end() && it->second.quality == quality && it->second.min_dist == min_dist &&
-        (it->second.exhausted || max_corners <= it->second.cap)) {
+    if (it != corner_cache_.end() && it->second.serves(max_corners, quality, min_dist)) {
       if (clk_) clk_->shi_memo_hits++;
-      return prefix(it->second.corners);
+      return it->second.prefix(max_corners);
     }
     if (prefetch_ && prefetch_->matches(quality, min_dist)) {  // computed ahead of time on the worker's context?
       std::vector<V2> seq;
@@ -67,7 +80,7 @@ std::vector<V2> GpuTracker::shi_tomasi(sfmx_pyramid* pyr, int max_corners, doubl
         auto& m = corner_cache_[frame_key];
         m = CornerMemo{quality, min_dist, 0x7fffffff, true, std::move(seq)};
         if (clk_) clk_->shi += since(t0);
-        return prefix(m.corners);
+        return m.prefix(max_corners);
       }
     }
   }
@@ -473,12 +486,15 @@ void CornerPrefetcher::run_resolver(Worker& w) {
 }
 
 void GpuTracker::reset(FrameSource& src, int fi) {
+  const int next = have_prev_ ? (slot_ + 1) % (int)ring_.size() : slot_;
+  if (before_load_) before_load_(fi);
   const auto t0 = Clock::now();
-  src.load(ctx_, fi, prev_);
+  src.load(ctx_, fi, ring_[(size_t)next]);
   if (clk_) clk_->upload += since(t0);
+  slot_ = next;
   have_prev_ = true;
   tracks_.clear();
-  for (const V2& p : shi_tomasi(prev_, cfg_.max_tracks, cfg_.quality, cfg_.min_distance, fi)) tracks_.push_back({next_id_++, p});
+  for (const V2& p : shi_tomasi(ring_[(size_t)slot_], cfg_.max_tracks, cfg_.quality, cfg_.min_distance, fi)) tracks_.push_back({next_id_++, p});
 }
 
 void klt_pairs(sfmx_ctx* ctx, const LKConfig& cfg, const sfmx_pyramid* a, const sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
@@ -500,23 +516,22 @@ void klt_pairs(sfmx_ctx* ctx, const LKConfig& cfg, const sfmx_pyramid* a, const 
     clk->klt_calls++;
   }
 }
-void GpuTracker::track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
-                             std::vector<std::uint8_t>& keep) {
-  klt_pairs(ctx_, cfg_, a, b, p0, fwd, keep, clk_);
-}
-
 StepOut GpuTracker::step(FrameSource& src, int fi) {
   if (!have_prev_ || tracks_.empty()) {  // T:341-344
     reset(src, fi);
     return {};
   }
+  const int next = (slot_ + 1) % (int)ring_.size();
+  if (before_load_) before_load_(fi);  // the slot's previous tenant must have been released by the geometry lane
   auto t0 = Clock::now();
-  src.load(ctx_, fi, cur_);  // pyr1; pyr0 is the cached pyramid of prev_ (identical to rebuilding it, T:345)
+  sfmx_pyramid* prev = ring_[(size_t)slot_];
+  sfmx_pyramid* cur = ring_[(size_t)next];
+  src.load(ctx_, fi, cur);  // pyr1; pyr0 is the cached pyramid of the previous frame (identical to rebuilding it, T:345)
   if (clk_) clk_->upload += since(t0);
   std::vector<V2> p0(tracks_.size()), fwd;
   std::vector<std::uint8_t> keep;
   for (size_t i = 0; i < tracks_.size(); i++) p0[i] = tracks_[i].p;
-  track_pairs(prev_, cur_, p0, fwd, keep);
+  klt_pairs(ctx_, cfg_, prev, cur, p0, fwd, keep, clk_);
   StepOut out;
   std::vector<Track> kept;
   kept.reserve(tracks_.size());
@@ -530,11 +545,11 @@ StepOut GpuTracker::step(FrameSource& src, int fi) {
     out.cur_pts.push_back(fwd[i]);
     out.ids.push_back(tracks_[i].id);
   }
-  std::swap(prev_, cur_);  // prev_ = gray (T:370)
+  slot_ = next;  // prev_ = gray (T:370)
   tracks_ = std::move(kept);
   if ((int)tracks_.size() < cfg_.min_tracks) {  // replenish (T:374-389)
     const int need = cfg_.max_tracks - (int)tracks_.size();
-    const auto pts = shi_tomasi(prev_, need * 3, cfg_.quality, cfg_.min_distance, fi);
+    const auto pts = shi_tomasi(cur, need * 3, cfg_.quality, cfg_.min_distance, fi);
     t0 = Clock::now();
     // distance filter against all live tracks (incl. the ones appended here): existence test, so a
     // grid over track positions gives the same answer as the reference's linear scan.
@@ -937,6 +952,127 @@ float dot_desc(const std::vector<float>& a, const std::vector<float>& b) {
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------ tracker lane
+void StageClock::add(const StageClock& o) {
+  klt += o.klt; shi += o.shi; ransac += o.ransac; ba += o.ba; upload += o.upload; host += o.host; total += o.total; shi_gpu += o.shi_gpu;
+  shi_replay += o.shi_replay; desc += o.desc; bookkeeping += o.bookkeeping;
+  r_pre += o.r_pre; r_gpu += o.r_gpu; r_verify += o.r_verify; r_decomp += o.r_decomp; tri_iter += o.tri_iter; tri_solve += o.tri_solve;
+  tri_insert += o.tri_insert;
+  klt_kernel_us += o.klt_kernel_us; ransac_kernel_us += o.ransac_kernel_us; ba_kernel_us += o.ba_kernel_us; shi_kernel_us += o.shi_kernel_us;
+  lk_steps += o.lk_steps; tracks_in += o.tracks_in; ransac_calls += o.ransac_calls; ransac_points += o.ransac_points; ba_calls += o.ba_calls;
+  ba_iters += o.ba_iters; klt_calls += o.klt_calls; ransac_verified += o.ransac_verified; shi_fallbacks += o.shi_fallbacks;
+  shi_calls += o.shi_calls; shi_memo_hits += o.shi_memo_hits; shi_prefetched += o.shi_prefetched;
+  shi_wait += o.shi_wait; setup += o.setup;
+  pf_busy += o.pf_busy; pf_gpu += o.pf_gpu; pf_replay += o.pf_replay; lane_b_busy += o.lane_b_busy; lane_c_busy += o.lane_c_busy;
+  join_wait += o.join_wait; ba_gather += o.ba_gather; m_step += o.m_step; m_ransac += o.m_ransac; m_kf += o.m_kf; feed_wait += o.feed_wait;
+}
+
+FrameFeeder::FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig& cfg, int extra_levels, int desc_level, int n_frames,
+                         bool threaded, CornerPrefetcher* prefetch, int prefetch_depth, StageClock* clk)
+    : src_(src), desc_level_(desc_level), n_frames_(n_frames), prefetch_depth_(prefetch_depth), prefetch_(prefetch), ctx_(caller_ctx), clk_(clk) {
+  if (threaded) {
+    pc_ = ContextPool::instance().acquire(sfmx_ctx_device(caller_ctx), prio_env("SFMX_PRIO_TRACKER", 0));
+    ctx_ = pc_->ctx;
+    if (sfmx_get_timing(caller_ctx)) (void)sfmx_set_timing(ctx_, 1);
+    clk_ = &lane_clk_;
+    ring_ = 6;
+  }
+  try {
+    std::function<void(int)> hook;
+    if (threaded)
+      hook = [this](int fi) {  // frame fi is about to overwrite the pyramid of frame fi - ring
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_rel_.wait(lk, [&] { return stop_ || released_ >= fi - ring_; });
+        if (stop_) throw SfmxFailure(SFMX_ERR_INVALID, "tracker lane stopped");
+      };
+    tracker_ = std::make_unique<GpuTracker>(ctx_, cfg, src.width(), src.height(), extra_levels, clk_, ring_, hook);
+    tracker_->set_prefetcher(prefetch_);
+    if (threaded) th_ = std::thread([this] { run(); });
+  } catch (...) {
+    tracker_.reset();
+    if (pc_) ContextPool::instance().release(pc_);
+    throw;
+  }
+}
+FrameFeeder::~FrameFeeder() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_rel_.notify_all();
+  cv_pkt_.notify_all();
+  if (th_.joinable()) th_.join();
+  tracker_.reset();  // its pyramids live on the lane's context
+  if (pc_) ContextPool::instance().release(pc_);
+}
+FramePacket FrameFeeder::produce(int fi) {
+  if (prefetch_) {
+    prefetch_->discard_older_than(fi);  // results nobody asked for (no replenish on that frame)
+    for (int a = 1; a <= prefetch_depth_; ++a)
+      if (fi + a < n_frames_) prefetch_->request(fi + a);
+  }
+  FramePacket p;
+  p.fi = fi;
+  const auto t0 = Clock::now();
+  p.step = tracker_->step(src_, fi);
+  p.tracks = tracker_->tracks();
+  p.pyr = tracker_->current();
+  p.corners = tracker_->take_memo(fi);
+  clk_->m_step += since(t0);
+  const auto td = Clock::now();
+  p.desc = global_desc_32(ctx_, tracker_->current(), desc_level_);
+  clk_->desc += since(td);
+  return p;
+}
+void FrameFeeder::run() {
+  (void)sfmx_ctx_make_current(ctx_);
+  try {
+    for (int fi = 0; fi < n_frames_; ++fi) {
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (stop_) break;
+      }
+      FramePacket p = produce(fi);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        queue_.push_back(std::move(p));
+      }
+      cv_pkt_.notify_one();
+    }
+  } catch (...) {
+    std::lock_guard<std::mutex> lk(mu_);
+    error_ = std::current_exception();
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    done_ = true;
+  }
+  cv_pkt_.notify_all();
+}
+FramePacket FrameFeeder::next() {
+  if (!pc_) return produce(next_frame_++);
+  std::unique_lock<std::mutex> lk(mu_);
+  cv_pkt_.wait(lk, [&] { return !queue_.empty() || done_; });
+  if (queue_.empty()) {
+    if (error_) std::rethrow_exception(error_);
+    throw SfmxFailure(SFMX_ERR_INVALID, "tracker lane ended early");
+  }
+  FramePacket p = std::move(queue_.front());
+  queue_.pop_front();
+  return p;
+}
+void FrameFeeder::finish() {
+  if (th_.joinable()) th_.join();
+}
+void FrameFeeder::release_upto(int frame) {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (frame <= released_) return;
+    released_ = frame;
+  }
+  cv_rel_.notify_all();
+}
+
 void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>& meta, const Mat3& K, const PipelineConfig& cfg,
                   PipelineResult& out, void (*echo)(const std::string&)) {
   const auto t_all = Clock::now();
@@ -944,7 +1080,6 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   const int w = src.width(), h = src.height();
   const int dlevel = desc_level(w, h);
   if (dlevel + 1 > 8 || cfg.klt.pyr_levels > 8) throw SfmxFailure(SFMX_ERR_UNSUPPORTED, "image too large for an 8-level pyramid");
-  GpuTracker tracker(ctx, cfg.klt, w, h, dlevel + 1, &clk);
   // one worker keeps frame f+1 in flight; more (SFMX_PREFETCH_WORKERS) remove the residual wait but the extra
   // contexts slow the other lanes down by more than that on one GPU (measured: 1 -> 552, 2 -> 498, 3 -> 510 kf/s)
   int prefetch_workers = 1;
@@ -952,8 +1087,13 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   std::unique_ptr<CornerPrefetcher> prefetch;
   if (!std::getenv("SFMX_NO_PREFETCH") && std::min(cfg.frames, src.count()) > 1 && cfg.klt.min_distance >= 1 && cfg.klt.min_distance <= 16) {
     prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance, prefetch_workers, sfmx_get_timing(ctx) != 0);
-    tracker.set_prefetcher(prefetch.get());
   }
+  // Tracker lane (FrameFeeder): SFMX_NO_ASYNC / SFMX_NO_TRACK_LANE run KLTTracker::step inline on the caller's context.
+  const int n_frames = std::min(cfg.frames, src.count());
+  const bool track_lane = !std::getenv("SFMX_NO_ASYNC") && !std::getenv("SFMX_NO_TRACK_LANE") && n_frames > 1;
+  FrameFeeder feeder(ctx, src, cfg.klt, dlevel + 1, dlevel, n_frames, track_lane, prefetch.get(), prefetch_workers + 1, &clk);
+  CornerDetector geo_det(ctx, &clk);                                  // loop closure: corners of old keyframe images ...
+  std::unordered_map<int, std::shared_ptr<const CornerMemo>> kf_corners;  // ... unless their sequence is already known
   // Lane B: the keyframe->keyframe RANSAC (its edge only feeds the pose graph / CSV) and the local BA of keyframe k
   // do not feed frame k+1's tracking or frame->frame RANSAC, so they run on a second context while the main
   // thread goes on; they are joined before the next keyframe is built (triangulation reads the refined poses)
@@ -1053,28 +1193,28 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   clk.setup = since(t_all);
   for (int fi = 0; fi < std::min(frames, src.count()); ++fi) {
     if (pending_loop.active && fi >= pending_loop.frame + 2) join_lane();  // its 'current' pyramid is about to be reused
-    if (prefetch) {
-      prefetch->discard_older_than(fi);  // results nobody asked for (no replenish on that frame)
-      for (int a = 1; a <= prefetch_workers + 1; ++a)  // per worker one image on the device and one in tie resolution
-        if (fi + a < std::min(frames, src.count())) prefetch->request(fi + a);
-    }
     const auto tm0 = Clock::now();
-    StepOut step = tracker.step(src, fi);
-    clk.m_step += since(tm0);
+    FramePacket pkt = feeder.next();
+    clk.feed_wait += since(tm0);
+    const StepOut& step = pkt.step;
+    // pyramids of finished frames go back to the tracker lane; a pending verification still reads its keyframe's
+    auto release_frames = [&](int done) { feeder.release_upto(pending_loop.active ? std::min(done, pending_loop.frame - 1) : done); };
     if (step.prev_pts.empty()) {  // first keyframe (T:1715-1733)
       Keyframe kf(arena);
       kf.kf_id = (int)kfs.size();
       kf.frame_idx = fi;
       kf.img_name = meta[(size_t)fi].name;
       kf.pose = cur;
-      kf_desc.push_back(global_desc_32(ctx, tracker.current(), dlevel));
-      for (const Track& tr : tracker.tracks()) {
+      kf_desc.push_back(pkt.desc);
+      if (pkt.corners) kf_corners[fi] = pkt.corners;
+      for (const Track& tr : pkt.tracks) {
         kf.obs.emplace(tr.id, tr.p);
         track_hist[tr.id].obs.push_back({kf.kf_id, tr.p});
       }
       kfs.push_back(std::move(kf));
       last_kf_frame = fi;
       emit(fi);
+      release_frames(fi);
       continue;
     }
     const std::vector<V2>& p_i = step.prev_pts;
@@ -1112,11 +1252,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       kf.frame_idx = fi;
       kf.img_name = meta[(size_t)fi].name;
       kf.pose = cur;
-      const auto td0 = Clock::now();
-      const auto new_desc = global_desc_32(ctx, tracker.current(), dlevel);
-      clk.desc += since(td0);
+      const std::vector<float>& new_desc = pkt.desc;
+      if (pkt.corners) kf_corners[fi] = pkt.corners;
       const auto tb0 = Clock::now();
-      for (const Track& tr : tracker.tracks()) {
+      for (const Track& tr : pkt.tracks) {
         kf.obs.emplace(tr.id, tr.p);
         TrackHist& th = track_hist[tr.id];
         th.obs.push_back({kf.kf_id, tr.p});
@@ -1206,19 +1345,32 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         LKConfig lc = cfg.klt;
         lc.max_tracks = 1200;
         lc.min_tracks = 600;
-        // corners of the old keyframe image: memoised when that frame was current (same image, quality, min_dist)
-        if (!old_pyr && !tracker.has_corners(old_kf.frame_idx, lc.quality, lc.min_distance, lc.max_tracks)) {
-          check(ctx, sfmx_pyramid_create(ctx, w, h, tracker.levels_total(), &old_pyr), "pyramid_create");
+        // corners of the old keyframe image (T:1841): a prefix of the sequence found when that frame was current (same
+        // image, quality, min_dist); detected here only if the tracker never replenished on that frame
+        std::vector<V2> pts0;
+        {
+          const auto ts0 = Clock::now();
+          clk.shi_calls++;
+          auto itc = kf_corners.find(old_kf.frame_idx);
+          if (itc != kf_corners.end() && itc->second->serves(lc.max_tracks, lc.quality, lc.min_distance)) {
+            clk.shi_memo_hits++;
+            pts0 = itc->second->prefix(lc.max_tracks);
+          } else {
+            if (!old_pyr) check(ctx, sfmx_pyramid_create(ctx, w, h, feeder.levels_total(), &old_pyr), "pyramid_create");
+            src.load(ctx, old_kf.frame_idx, old_pyr);
+            pts0 = geo_det.detect(old_pyr, lc.max_tracks, lc.quality, lc.min_distance);
+            kf_corners[old_kf.frame_idx] = std::make_shared<const CornerMemo>(
+                CornerMemo{lc.quality, lc.min_distance, lc.max_tracks, (int)pts0.size() < lc.max_tracks, pts0});
+          }
+          clk.shi += since(ts0);
         }
-        if (!tracker.has_corners(old_kf.frame_idx, lc.quality, lc.min_distance, lc.max_tracks)) src.load(ctx, old_kf.frame_idx, old_pyr);
-        auto pts0 = tracker.shi_tomasi(old_pyr, lc.max_tracks, lc.quality, lc.min_distance, old_kf.frame_idx);
         pending_loop = PendingLoop{true, fi, old_kf.kf_id, new_kf_id, std::nullopt};
         const int old_frame = old_kf.frame_idx;
-        const sfmx_pyramid* cur_pyr = tracker.current();  // stays intact until the frame after next is loaded
+        const sfmx_pyramid* cur_pyr = pkt.pyr;  // not released to the tracker lane while this verification is pending
         auto verify = [&, lc, old_frame, cur_pyr, pts0 = std::move(pts0)]() {
           sfmx_pyramid* opc = old_pyr_c;
-          if (lane_c) opc = lane_c->pooled()->pyramid(w, h, tracker.levels_total());  // lives with the pooled context
-          else if (!opc) { check(cctx, sfmx_pyramid_create(cctx, w, h, tracker.levels_total(), &old_pyr_c), "pyramid_create"); opc = old_pyr_c; }
+          if (lane_c) opc = lane_c->pooled()->pyramid(w, h, feeder.levels_total());  // lives with the pooled context
+          else if (!opc) { check(cctx, sfmx_pyramid_create(cctx, w, h, feeder.levels_total(), &old_pyr_c), "pyramid_create"); opc = old_pyr_c; }
           src.load(cctx, old_frame, opc);
           std::vector<V2> fwd;
           std::vector<std::uint8_t> keep;
@@ -1236,10 +1388,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       }
     }
     clk.m_kf += since(tm2);
-    if (!make_kf) tracker.forget_corners(fi);  // only keyframe images are ever re-detected (loop closure)
     emit(fi);
+    release_frames(fi);
   }
   join_lane();
+  feeder.finish();
+  if (feeder.threaded()) clk.add(feeder.lane_clock());
   if (lane) clk.lane_b_busy = lane->busy_seconds();
   if (lane_c) clk.lane_c_busy = lane_c->busy_seconds();
   if (lane_c) {
@@ -1257,7 +1411,6 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   }
   out.log = so.str();
   if (prefetch) {
-    tracker.set_prefetcher(nullptr);
     clk.shi_fallbacks += prefetch->replays();
     clk.shi_kernel_us += prefetch->kernel_us();
     prefetch->busy(clk.pf_busy, clk.pf_gpu, clk.pf_replay);  // the worker's tie-order replays count too
@@ -1329,7 +1482,7 @@ struct sfmx_pipeline_stats {
   unsigned long long lk_steps, tracks_in, klt_calls, ransac_calls, ransac_points, ba_calls, ba_iters, ransac_verified, shi_fallbacks, shi_calls, shi_memo_hits, shi_prefetched;
   double sec_shi_wait, sec_setup, sec_wall;
   double sec_pf_busy, sec_pf_gpu, sec_pf_replay, sec_lane_b_busy, sec_lane_c_busy, sec_join_wait, sec_ba_gather;
-  double sec_m_step, sec_m_ransac, sec_m_kf;
+  double sec_m_step, sec_m_ransac, sec_m_kf, sec_feed_wait;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -1376,7 +1529,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
                                    c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait, c.setup, wall,
                                    c.pf_busy, c.pf_gpu, c.pf_replay, c.lane_b_busy, c.lane_c_busy, c.join_wait, c.ba_gather,
-                                   c.m_step, c.m_ransac, c.m_kf};
+                                   c.m_step, c.m_ransac, c.m_kf, c.feed_wait};
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {

@@ -72,7 +72,9 @@ struct StageClock {
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
   double shi_wait = 0, setup = 0;
   double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_b_busy = 0, lane_c_busy = 0, join_wait = 0, ba_gather = 0;
-  double m_step = 0, m_ransac = 0, m_kf = 0;  // main-lane wall time: tracker.step / frame->frame RANSAC / keyframe block
+  double m_step = 0, m_ransac = 0, m_kf = 0;  // wall time of tracker.step (tracker lane) / frame->frame RANSAC / keyframe block
+  double feed_wait = 0;                        // geometry lane waiting for the tracker lane
+  void add(const StageClock& o);               // field-wise sum (lane clocks are folded into the run's clock)
 };
 
 // shi_tomasi (T:237-302) on one context: device score + certain-outcome fixpoint (sfmx_shi_tomasi_candidates_pruned),
@@ -182,32 +184,41 @@ class CornerPrefetcher {
   bool stop_ = false;
 };
 
+// The accepted-corner sequence of one image: the greedy pick accepts candidates in a fixed order and max_corners only
+// truncates it, so any request with the same quality / min_dist and max_corners <= cap (or any, if the pick ran to
+// exhaustion) is a prefix of it.
+struct CornerMemo {
+  double quality;
+  int min_dist;
+  int cap;
+  bool exhausted;
+  std::vector<V2> corners;
+  bool serves(int max_corners, double q, int md) const { return max_corners >= 1 && quality == q && min_dist == md && (exhausted || max_corners <= cap); }
+  std::vector<V2> prefix(int max_corners) const {
+    return std::vector<V2>(corners.begin(), corners.begin() + (long)std::min((size_t)std::max(max_corners, 0), corners.size()));
+  }
+};
+
 // KLTTracker (T:323-466) on the GPU
 class GpuTracker {
  public:
-  GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk);
+  // ring >= 2 pyramids: the k-th processed frame lives in slot k % ring.  before_load(fi), if set, is called before
+  // frame fi overwrites the slot of frame fi - ring (the tracker lane waits there until that frame is released).
+  GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk, int ring = 2,
+             std::function<void(int)> before_load = nullptr);
   ~GpuTracker();
   GpuTracker(const GpuTracker&) = delete;
   GpuTracker& operator=(const GpuTracker&) = delete;
   StepOut step(FrameSource& src, int fi);
   const std::vector<Track>& tracks() const { return tracks_; }
-  sfmx_pyramid* current() const { return prev_; }  // pyramid of the most recent frame
+  sfmx_pyramid* current() const { return ring_[(size_t)slot_]; }  // pyramid of the most recent frame
   const LKConfig& cfg() const { return cfg_; }
   // shi_tomasi (T:237-302): device score + certain-outcome fixpoint, host sort + greedy pick on the survivors.
-  // frame_key >= 0 memoises the accepted-corner sequence of that frame: the greedy pick accepts candidates in
-  // a fixed order and max_corners only truncates it, so a later call on the same image with the same
-  // quality / min_dist (the loop-closure verification re-detects corners on old keyframe images, T:1841)
-  // is a prefix of the stored sequence.
+  // frame_key >= 0 memoises the accepted-corner sequence of that frame (CornerMemo).
   std::vector<V2> shi_tomasi(sfmx_pyramid* pyr, int max_corners, double quality, int min_dist, int frame_key = -1);
-  void forget_corners(int frame_key) { corner_cache_.erase(frame_key); }
-  bool has_corners(int frame_key, double quality, int min_dist, int max_corners) const {
-    auto it = corner_cache_.find(frame_key);
-    return it != corner_cache_.end() && it->second.quality == quality && it->second.min_dist == min_dist && max_corners >= 1 &&
-           (it->second.exhausted || max_corners <= it->second.cap);
-  }
+  // hands the memo of a frame over (the loop-closure verification re-detects corners on old keyframe images, T:1841)
+  std::shared_ptr<const CornerMemo> take_memo(int frame_key);
   void set_prefetcher(CornerPrefetcher* p) { prefetch_ = p; }
-  // fwd/bwd track of arbitrary points between two pyramids (loop-closure verification, T:1847-1854)
-  void track_pairs(sfmx_pyramid* a, sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd, std::vector<std::uint8_t>& keep);
   int levels_total() const { return levels_total_; }
 
  private:
@@ -215,8 +226,9 @@ class GpuTracker {
   sfmx_ctx* ctx_;
   LKConfig cfg_;
   int w_, h_, levels_total_;
-  sfmx_pyramid* prev_ = nullptr;
-  sfmx_pyramid* cur_ = nullptr;
+  std::vector<sfmx_pyramid*> ring_;
+  int slot_ = 0;
+  std::function<void(int)> before_load_;
   bool have_prev_ = false;
   std::vector<Track> tracks_;
   std::vector<int> grid_head_, grid_next_;  // scratch of the replenish distance filter
@@ -224,8 +236,55 @@ class GpuTracker {
   StageClock* clk_;
   CornerDetector det_;
   CornerPrefetcher* prefetch_ = nullptr;
-  struct CornerMemo { double quality; int min_dist; int cap; bool exhausted; std::vector<V2> corners; };
   std::unordered_map<int, CornerMemo> corner_cache_;
+};
+
+// What the geometry lane needs of one frame.  pyr stays valid until FrameFeeder::release_upto(fi).
+struct FramePacket {
+  int fi = -1;
+  StepOut step;                                  // empty prev_pts: the tracker (re)started on this frame (T:341-344)
+  std::vector<Track> tracks;                     // live tracks after the step, replenished ones included
+  const sfmx_pyramid* pyr = nullptr;             // this frame's pyramid (tracker context, same device)
+  std::vector<float> desc;                       // global_desc_32 of the frame (T:1100-1122)
+  std::shared_ptr<const CornerMemo> corners;     // accepted-corner sequence, if this frame's image was detected
+};
+
+// Tracker lane.  KLTTracker::step depends on the images and on its own previous state only -- never on poses, keyframe
+// decisions or the map -- so frame f+1.. are tracked on a context of their own while the geometry lane (RANSAC,
+// keyframes, triangulation, BA hand-over) is still busy with frame f.  The ring of pyramids bounds how far it runs
+// ahead; inline mode (threaded = false) produces each packet inside next() on the caller's context.
+class FrameFeeder {
+ public:
+  FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig& cfg, int extra_levels, int desc_level, int n_frames, bool threaded,
+              CornerPrefetcher* prefetch, int prefetch_depth, StageClock* clk);
+  ~FrameFeeder();
+  FrameFeeder(const FrameFeeder&) = delete;
+  FrameFeeder& operator=(const FrameFeeder&) = delete;
+  FramePacket next();             // packets arrive in frame order; rethrows what the tracker lane threw
+  void release_upto(int frame);   // the pyramids of frames <= frame may be overwritten
+  void finish();                  // waits for the lane to end (all packets produced); its clock may be read afterwards
+  int levels_total() const { return tracker_->levels_total(); }
+  bool threaded() const { return pc_ != nullptr; }
+  StageClock& lane_clock() { return lane_clk_; }  // the tracker lane's own counters (threaded mode; read after the run)
+
+ private:
+  FramePacket produce(int fi);
+  void run();
+  FrameSource& src_;
+  int desc_level_, n_frames_, next_frame_ = 0, ring_ = 2, prefetch_depth_;
+  CornerPrefetcher* prefetch_;
+  PooledCtx* pc_ = nullptr;
+  sfmx_ctx* ctx_;
+  StageClock lane_clk_;
+  StageClock* clk_;
+  std::unique_ptr<GpuTracker> tracker_;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_pkt_, cv_rel_;
+  std::deque<FramePacket> queue_;
+  int released_ = -1;
+  bool stop_ = false, done_ = false;
+  std::exception_ptr error_;
 };
 
 // fwd/bwd track of arbitrary points between two pyramids on any context of the same device (loop-closure verification)

@@ -37,7 +37,7 @@ class PipelineStats(ctypes.Structure):
                 ("sec_setup", c_double), ("sec_wall", c_double), ("sec_pf_busy", c_double), ("sec_pf_gpu", c_double),
                 ("sec_pf_replay", c_double), ("sec_lane_b_busy", c_double), ("sec_lane_c_busy", c_double),
                 ("sec_join_wait", c_double), ("sec_ba_gather", c_double), ("sec_m_step", c_double), ("sec_m_ransac", c_double),
-                ("sec_m_kf", c_double)]
+                ("sec_m_kf", c_double), ("sec_feed_wait", c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

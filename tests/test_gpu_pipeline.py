@@ -145,8 +145,8 @@ def test_shi_fast_path_equals_full_sort(tmp_path):
 
 
 def test_async_lanes_do_not_change_results(tmp_path):
-    """Corner prefetch (worker context) and lane B (async kf->kf RANSAC + BA) only reorder WHEN work happens:
-    outputs must be byte-identical to the fully serial schedule (SFMX_NO_PREFETCH / SFMX_NO_ASYNC / SFMX_NO_GRAPH)."""
+    """The tracker lane, the corner prefetch worker and lanes B / C (async BA, kf->kf RANSAC, loop-closure verification)
+    only reorder WHEN work happens: outputs must be byte-identical to the fully serial schedule, whichever subset is on."""
     g = np.load(os.path.join(H.GOLDEN, "e2e_loop.npz"))
     cfgj = json.loads(str(g["config"]))
     names = [str(s) for s in g["names"]]
@@ -155,7 +155,8 @@ def test_async_lanes_do_not_change_results(tmp_path):
     with open(os.path.join(root, "cfg.json"), "w") as f:
         json.dump(cfgj, f)
     outs = []
-    for extra in ({}, {"SFMX_NO_PREFETCH": "1", "SFMX_NO_ASYNC": "1", "SFMX_NO_GRAPH": "1"}, {"SFMX_NO_ASYNC": "1"}, {"SFMX_NO_PREFETCH": "1"}):
+    for extra in ({}, {"SFMX_NO_PREFETCH": "1", "SFMX_NO_ASYNC": "1", "SFMX_NO_GRAPH": "1"}, {"SFMX_NO_ASYNC": "1"}, {"SFMX_NO_PREFETCH": "1"},
+                  {"SFMX_NO_TRACK_LANE": "1"}, {"SFMX_NO_TRACK_LANE": "1", "SFMX_NO_PREFETCH": "1", "SFMX_NO_CTX_POOL": "1"}):
         out = os.path.join(root, f"out{len(outs)}")
         p = subprocess.run([pipe.CLI_PATH, root, out, "--config", os.path.join(root, "cfg.json")], capture_output=True, text=True,
                            cwd=root, env={**os.environ, **extra})
