@@ -444,6 +444,127 @@ __global__ __launch_bounds__(64) void k_solve_wave(const double* __restrict__ Ai
   if (lane < n) x[lane] = xs[lane];
 }
 
+// k_solve_regs<N> (N = 6*W for the usual windows): ONE wavefront, lane = matrix row held in REGISTERS (the k and j
+// loops are fully unrolled, so every a[j] is a fixed VGPR); LDS only carries the pivot row of each step.  Compared with
+// k_solve_wave this removes the dependent LDS round trips of the elimination (the dominant cost: ~3500 cycles per step).
+//   rows are never moved: each lane tracks the POSITION its row currently has in the reference's matrix; a row swap
+//     (dense.hpp:69-72) exchanges two positions, and "first strictly larger" = smallest position among the maxima;
+//   pivot   : |a[k]| of the lanes at positions >= k, DPP wave-max, DPP wave-min of the candidates' positions;
+//   scale   : the pivot lane spills its row (and b as column N) to LDS, lane j divides element j (one IEEE division
+//             instruction for the whole row), every lane reads the normalised row back as broadcasts;
+//   eliminate: lanes at positions > k with |f| >= 1e-18: a[j] -= f * r[j] in registers;
+//   back-substitution: the lane at position i runs the reference's ascending-j subtraction chain over products
+//             a[j]*x[j] that every lane forms for its own row as soon as x[j] exists.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min_step_i32(int m) {
+  const int t = __builtin_amdgcn_update_dpp(m, m, CTRL, ROW_MASK, 0xF, false);
+  return t < m ? t : m;
+}
+__device__ __forceinline__ int wave_min_i32(int m) {
+  m = dpp_min_step_i32<0xB1, 0xF>(m);
+  m = dpp_min_step_i32<0x4E, 0xF>(m);
+  m = dpp_min_step_i32<0x141, 0xF>(m);
+  m = dpp_min_step_i32<0x140, 0xF>(m);
+  m = dpp_min_step_i32<0x142, 0xA>(m);
+  m = dpp_min_step_i32<0x143, 0xC>(m);
+  return __builtin_amdgcn_readlane(m, 63);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void k_solve_regs(const double* __restrict__ Ain, const double* __restrict__ bin, double* __restrict__ x,
+                                                   int* __restrict__ status) {
+  static_assert(N >= 2 && N <= 62, "b rides along as column N: lane N must exist");
+  constexpr int LD = N | 1;
+  __shared__ double stage[N * LD];
+  __shared__ double rowbuf[N + 2];
+  const int lane = threadIdx.x;
+  for (int e = lane; e < N * N; e += 64) stage[(e / N) * LD + (e % N)] = Ain[e];
+  __syncthreads();
+  const int row = lane < N ? lane : N - 1;  // lanes >= N shadow the last row and never take part
+  double a[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) a[j] = stage[row * LD + j];
+  double bv = bin[row];
+  int pos = lane < N ? lane : 0x3fffffff;  // position of this lane's row; finished pivot rows keep position k
+  bool done = lane >= N;                   // true once the row has been a pivot row
+  double xr = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    // ---- pivot (dense.hpp:61-67)
+    const bool cand_row = !done;
+    const double v = cand_row ? fabs(a[k]) : -1.0;
+    const int lane_k = (int)__builtin_ctzll(__ballot(cand_row && pos == k));
+    const double akk0 = readlane_f64(v, lane_k);
+    int pivpos = k, lane_p = lane_k;
+    double best = akk0;
+    if (akk0 == akk0) {  // a NaN on the diagonal stays the pivot: `v > NaN` is never true
+      const double m = wave_max_f64((v == v) ? v : -1.0);
+      const unsigned long long hits = __ballot(cand_row && v == m);
+      if (__builtin_popcountll(hits) == 1) {  // the usual case: a unique maximum
+        lane_p = (int)__builtin_ctzll(hits);
+        pivpos = __builtin_amdgcn_readlane(pos, lane_p);
+      } else {  // ties: the reference keeps the first one in position order
+        pivpos = wave_min_i32((cand_row && v == m) ? pos : 0x7fffffff);
+        lane_p = (int)__builtin_ctzll(__ballot(cand_row && pos == pivpos));
+      }
+      best = m;
+    }
+    if (best < 1e-15) {
+      if (lane == 0) status[0] = 1;
+      return;
+    }
+    // ---- row swap (dense.hpp:69-72) = exchange of positions
+    if (lane == lane_k) pos = pivpos;
+    if (lane == lane_p) { pos = k; done = true; }
+    // ---- normalise the pivot row (dense.hpp:74-76) through LDS, transposed: one division per lane
+    if (lane == lane_p) {
+#pragma unroll
+      for (int j = k; j < N; j++) rowbuf[j] = a[j];
+      rowbuf[N] = bv;
+    }
+    __syncthreads();
+    {
+      const double akk = rowbuf[k];
+      const int j = lane < k ? k : (lane > N ? N : lane);
+      const double q = rowbuf[j] / akk;
+      __syncthreads();
+      if (lane >= k && lane <= N) rowbuf[lane] = q;
+    }
+    __syncthreads();
+    // ---- eliminate (dense.hpp:78-83); the pivot lane takes its normalised row back
+    const bool is_p = lane == lane_p;
+    const double f = a[k];
+    const bool upd = !done && !(fabs(f) < 1e-18);
+    if (upd || is_p) {
+      const double g = is_p ? 0.0 : f;  // pivot lane: a[j] = r[j] (selected below), others: a[j] - f * r[j]
+#pragma unroll
+      for (int j = k; j < N; j++) {
+        const double r = rowbuf[j];
+        a[j] = is_p ? r : a[j] - g * r;
+      }
+      const double rb = rowbuf[N];
+      bv = is_p ? rb : bv - g * rb;
+    }
+    __syncthreads();  // rowbuf is rewritten by the next step
+  }
+  // ---- back substitution (dense.hpp:86-91): after the loop every lane < N sits at a distinct position
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
+    const int lane_i = (int)__builtin_ctzll(__ballot(pos == i));
+    double s = bv;
+#pragma unroll
+    for (int j = i + 1; j < N; j++) s -= a[j];  // a[j] already holds A(.,j)*x[j] for this lane's row
+    const double xi = readlane_f64(s, lane_i);
+    a[i] = a[i] * xi;  // the product the reference forms at dense.hpp:89, for every row at once
+    if (lane == i) xr = xi;
+  }
+  if (lane == 0) status[0] = 0;
+  if (lane < N) x[lane] = xr;
+}
+
 // Larger systems: one 256-thread workgroup, matrix in LDS (n <= 141) or in a global working copy.
 template <bool IN_LDS>
 __global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ Ain, const double* __restrict__ bin, int n,
@@ -559,7 +680,11 @@ static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, 
     SFMX_HIP(c, hipFuncSetAttribute((const void*)k_solve_gauss<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem(SOLVE_LDS_MAX_N)));
     attr_set = true;
   }
-  if (n <= SOLVE_WAVE_MAX_N) {
+  if (n == 36) {  // window of 6 (the reference default) and of 10 (C4): rows in registers
+    k_solve_regs<36><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus);
+  } else if (n == 60) {
+    k_solve_regs<60><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus);
+  } else if (n <= SOLVE_WAVE_MAX_N) {
     k_solve_wave<<<1, 64, 0, c->stream>>>(dA, db, n, dx, dstatus);
   } else if (n <= SOLVE_LDS_MAX_N) {
     k_solve_gauss<true><<<1, 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus, nullptr);

@@ -34,9 +34,15 @@ void MemoryFrames::load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) {
 }
 
 // ------------------------------------------------------------------------------------------ tracker
-GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk, int ring, std::function<void(int)> before_load)
+GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk, int ring, std::function<void(int)> before_load,
+                       const std::vector<sfmx_pyramid*>* borrowed)
     : ctx_(ctx), cfg_(cfg), w_(w), h_(h), before_load_(std::move(before_load)), clk_(clk), det_(ctx, clk) {
   levels_total_ = std::max(cfg.pyr_levels, extra_levels);
+  if (borrowed) {
+    ring_ = *borrowed;
+    owns_ring_ = false;
+    return;
+  }
   try {
     for (int i = 0; i < std::max(2, ring); i++) {
       sfmx_pyramid* p = nullptr;
@@ -49,7 +55,8 @@ GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_leve
   }
 }
 GpuTracker::~GpuTracker() {
-  for (sfmx_pyramid* p : ring_) sfmx_pyramid_destroy(ctx_, p);
+  if (owns_ring_)
+    for (sfmx_pyramid* p : ring_) sfmx_pyramid_destroy(ctx_, p);
 }
 
 std::shared_ptr<const CornerMemo> GpuTracker::take_memo(int frame_key) {
@@ -293,7 +300,7 @@ void ContextPool::release(PooledCtx* pc) {
   (void)sfmx_sync(pc->ctx);
   (void)sfmx_set_timing(pc->ctx, 0);
   if (no_pool) {
-    if (pc->pyr) sfmx_pyramid_destroy(pc->ctx, pc->pyr);
+    pc->free_pyramids();
     sfmx_ctx_destroy(pc->ctx);
     delete pc;
     return;
@@ -304,11 +311,30 @@ void ContextPool::release(PooledCtx* pc) {
 void ContextPool::clear() {
   std::lock_guard<std::mutex> lk(mu_);
   for (PooledCtx* pc : free_) {
-    if (pc->pyr) sfmx_pyramid_destroy(pc->ctx, pc->pyr);
+    pc->free_pyramids();
     sfmx_ctx_destroy(pc->ctx);
     delete pc;
   }
   free_.clear();
+}
+void PooledCtx::free_pyramids() {
+  if (pyr) sfmx_pyramid_destroy(ctx, pyr);
+  pyr = nullptr;
+  for (sfmx_pyramid* p : ring) sfmx_pyramid_destroy(ctx, p);
+  ring.clear();
+}
+const std::vector<sfmx_pyramid*>& PooledCtx::pyramid_ring(int w, int h, int levels, int count) {
+  if (!ring.empty() && (rw != w || rh != h || rl != levels || (int)ring.size() != count)) {
+    for (sfmx_pyramid* p : ring) sfmx_pyramid_destroy(ctx, p);
+    ring.clear();
+  }
+  while ((int)ring.size() < count) {
+    sfmx_pyramid* p = nullptr;
+    check(ctx, sfmx_pyramid_create(ctx, w, h, levels, &p), "pyramid_create(helper ring)");
+    ring.push_back(p);
+  }
+  rw = w; rh = h; rl = levels;
+  return ring;
 }
 sfmx_pyramid* PooledCtx::pyramid(int w, int h, int levels) {
   if (pyr && (pw != w || ph != h || pl != levels)) {
@@ -985,7 +1011,9 @@ FrameFeeder::FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig&
         cv_rel_.wait(lk, [&] { return stop_ || released_ >= fi - ring_; });
         if (stop_) throw SfmxFailure(SFMX_ERR_INVALID, "tracker lane stopped");
       };
-    tracker_ = std::make_unique<GpuTracker>(ctx_, cfg, src.width(), src.height(), extra_levels, clk_, ring_, hook);
+    const std::vector<sfmx_pyramid*>* borrowed = nullptr;
+    if (pc_) borrowed = &pc_->pyramid_ring(src.width(), src.height(), std::max(cfg.pyr_levels, extra_levels), ring_);
+    tracker_ = std::make_unique<GpuTracker>(ctx_, cfg, src.width(), src.height(), extra_levels, clk_, ring_, hook, borrowed);
     tracker_->set_prefetcher(prefetch_);
     if (threaded) th_ = std::thread([this] { run(); });
   } catch (...) {

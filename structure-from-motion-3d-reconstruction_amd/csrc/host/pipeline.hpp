@@ -90,6 +90,10 @@ struct PooledCtx {
   sfmx_pyramid* pyr = nullptr;  // one scratch pyramid that lives with the context
   int pw = 0, ph = 0, pl = 0;
   sfmx_pyramid* pyramid(int w, int h, int levels);  // (re)created when the geometry changes
+  std::vector<sfmx_pyramid*> ring;  // the tracker lane's pyramids, same life cycle
+  int rw = 0, rh = 0, rl = 0;
+  const std::vector<sfmx_pyramid*>& pyramid_ring(int w, int h, int levels, int count);
+  void free_pyramids();
 };
 class ContextPool {
  public:
@@ -204,8 +208,9 @@ class GpuTracker {
  public:
   // ring >= 2 pyramids: the k-th processed frame lives in slot k % ring.  before_load(fi), if set, is called before
   // frame fi overwrites the slot of frame fi - ring (the tracker lane waits there until that frame is released).
+  // borrowed: pyramids owned by somebody else (a pooled context); otherwise `ring` pyramids are created and owned here
   GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk, int ring = 2,
-             std::function<void(int)> before_load = nullptr);
+             std::function<void(int)> before_load = nullptr, const std::vector<sfmx_pyramid*>* borrowed = nullptr);
   ~GpuTracker();
   GpuTracker(const GpuTracker&) = delete;
   GpuTracker& operator=(const GpuTracker&) = delete;
@@ -227,6 +232,7 @@ class GpuTracker {
   LKConfig cfg_;
   int w_, h_, levels_total_;
   std::vector<sfmx_pyramid*> ring_;
+  bool owns_ring_ = true;
   int slot_ = 0;
   std::function<void(int)> before_load_;
   bool have_prev_ = false;
