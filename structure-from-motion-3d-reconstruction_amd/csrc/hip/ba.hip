@@ -56,6 +56,36 @@ __device__ __forceinline__ bool inv3_ref(const double* A, double* inv) {
   return true;
 }
 
+// Hxx (6x6), bx (6) and Hxp (6x3) of one residual added into a slot record (T:990-1009).  FRESH: the slot was created
+// by this very observation, so the reference's "zero-initialised block += v" is evaluated as 0.0 + v and stored without
+// reading the record back; otherwise (the same pose observes the point twice) it is a read-modify-write.
+template <bool FRESH>
+__device__ __forceinline__ void ba_accumulate_slot(double* __restrict__ A, const double* Jx, const double* Jp, double wgt, double rx, double ry) {
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      double s = 0.0;
+      s += Jx[a] * Jx[c];
+      s += Jx[6 + a] * Jx[6 + c];
+      A[a * 6 + c] = (FRESH ? 0.0 : A[a * 6 + c]) + wgt * s;
+    }
+    double sb = 0.0;
+    sb += Jx[a] * rx;
+    sb += Jx[6 + a] * ry;
+    A[36 + a] = (FRESH ? 0.0 : A[36 + a]) + wgt * sb;
+  }
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+      s += Jx[a] * Jp[c];
+      s += Jx[6 + a] * Jp[3 + c];
+      A[42 + a * 3 + c] = (FRESH ? 0.0 : A[42 + a * 3 + c]) + wgt * s;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_ba_points(int W, int P, int MS, const double* __restrict__ poses, const double* __restrict__ X,
                                                   const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
                                                   const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
@@ -77,17 +107,21 @@ __global__ __launch_bounds__(64) void k_ba_points(int W, int P, int MS, const do
     const int li = obs_li[o];
     if (li < 0 || li >= W) continue;  // malformed input: ignore (cannot occur through the host API)
     int ai = so[li];
-    if (ai < 0) {
+    const bool fresh = ai < 0;
+    if (fresh) {
       ai = na++;
       so[li] = (int8_t)ai;
-      double* z = prec + (size_t)ai * BA_SLOT;
-      for (int k = 0; k < 60; k++) z[k] = 0.0;
     }
+    double* A = prec + (size_t)ai * BA_SLOT;
     const double* R = sp + 12 * li;
     const double Xcx = (R[0] * Xx + R[1] * Xy + R[2] * Xz) + R[9];
     const double Xcy = (R[3] * Xx + R[4] * Xy + R[5] * Xz) + R[10];
     const double Xcz = (R[6] * Xx + R[7] * Xy + R[8] * Xz) + R[11];
-    if (Xcz <= 1e-6) continue;  // T:933 (NaN passes, as in the reference)
+    if (Xcz <= 1e-6) {  // T:933 (NaN passes, as in the reference); the slot exists (T:925-930) but stays zero
+      if (fresh)
+        for (int k = 0; k < 60; k++) A[k] = 0.0;
+      continue;
+    }
     const double qx = Xcx / Xcz, qy = Xcy / Xcz;
     const double rx = obs_uv[2 * o] - (fx * qx + cx);
     const double ry = obs_uv[2 * o + 1] - (fy * qy + cy);
@@ -128,30 +162,8 @@ __global__ __launch_bounds__(64) void k_ba_points(int W, int P, int MS, const do
       sb += Jp[3 + a] * ry;
       bp[a] += wgt * sb;
     }
-    double* A = prec + (size_t)ai * BA_SLOT;
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-#pragma unroll
-      for (int c = 0; c < 6; c++) {
-        double s = 0.0;
-        s += Jx[a] * Jx[c];
-        s += Jx[6 + a] * Jx[6 + c];
-        A[a * 6 + c] += wgt * s;
-      }
-      double sb = 0.0;
-      sb += Jx[a] * rx;
-      sb += Jx[6 + a] * ry;
-      A[36 + a] += wgt * sb;
-    }
-#pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        double s = 0.0;
-        s += Jx[a] * Jp[c];
-        s += Jx[6 + a] * Jp[3 + c];
-        A[42 + a * 3 + c] += wgt * s;
-      }
+    if (fresh) ba_accumulate_slot<true>(A, Jx, Jp, wgt, rx, ry);
+    else ba_accumulate_slot<false>(A, Jx, Jp, wgt, rx, ry);
   }
   double iH[9];
   if (!inv3_ref(Hpp, iH)) {  // T:1012: the point contributes nothing at all
