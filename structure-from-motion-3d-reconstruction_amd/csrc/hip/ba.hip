@@ -736,22 +736,36 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
   q->MS = W < BA_MAX_OBS ? W : BA_MAX_OBS;
   const int D = 6 * W;
   const size_t CS = (size_t)36 * W * W + 36 * W + 12 * W;
-  const size_t need[11] = {(size_t)P * 24, (size_t)(P + 1) * 4, (size_t)R * 4 + 8, (size_t)R * 16 + 8, (size_t)W * 96,
+  // the four input arrays share one device slab [X | obs_uv | obs_ptr | obs_li] (16-byte aligned parts) and travel
+  // in ONE transfer from a pinned staging slab; no host wait: the first step is ordered behind it on the stream
+  auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t o_x = 0, o_uv = up16((size_t)P * 24), o_ptr = o_uv + up16((size_t)R * 16), o_li = o_ptr + up16((size_t)(P + 1) * 4);
+  const size_t in_bytes = o_li + up16((size_t)R * 4) + 16;
+  const size_t need[11] = {in_bytes, 16, 16, 16, (size_t)W * 96,
                            (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8, (size_t)D * 8, (size_t)D * 8 + 64,
                            (size_t)P * CS * 8};
   for (int i = 0; i < 11; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
   q->contrib = q->bufs[10].as<double>();
-  q->X = q->bufs[0].as<double>(); q->obs_ptr = q->bufs[1].as<int32_t>(); q->obs_li = q->bufs[2].as<int32_t>();
-  q->obs_uv = q->bufs[3].as<double>(); q->poses = q->bufs[4].as<double>(); q->rec = q->bufs[5].as<double>();
+  char* in = q->bufs[0].as<char>();
+  q->X = reinterpret_cast<double*>(in + o_x); q->obs_uv = reinterpret_cast<double*>(in + o_uv);
+  q->obs_ptr = reinterpret_cast<int32_t*>(in + o_ptr); q->obs_li = reinterpret_cast<int32_t*>(in + o_li);
+  q->poses = q->bufs[4].as<double>(); q->rec = q->bufs[5].as<double>();
   q->slot_of = q->bufs[6].as<int8_t>(); q->S = q->bufs[7].as<double>(); q->b = q->bufs[8].as<double>();
   q->work = q->bufs[9].as<double>();
-  SFMX_HIP(c, hipMemcpyAsync(q->X, X, (size_t)P * 24, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(q->obs_ptr, obs_ptr, (size_t)(P + 1) * 4, hipMemcpyHostToDevice, c->stream));
-  if (R > 0) {
-    SFMX_HIP(c, hipMemcpyAsync(q->obs_li, obs_li, (size_t)R * 4, hipMemcpyHostToDevice, c->stream));
-    SFMX_HIP(c, hipMemcpyAsync(q->obs_uv, obs_uv, (size_t)R * 16, hipMemcpyHostToDevice, c->stream));
+  if (c->ba_upload_in_flight) {  // two resets in a row: the staging slab is still being read
+    SFMX_HIP(c, hipStreamSynchronize(c->stream));
+    c->ba_upload_in_flight = false;
   }
-  SFMX_HIP(c, hipStreamSynchronize(c->stream));  // caller buffers may be released on return
+  SFMX_HIP(c, c->h[4].ensure(in_bytes));
+  char* st = c->h[4].as<char>();
+  memcpy(st + o_x, X, (size_t)P * 24);
+  memcpy(st + o_ptr, obs_ptr, (size_t)(P + 1) * 4);
+  if (R > 0) {
+    memcpy(st + o_uv, obs_uv, (size_t)R * 16);
+    memcpy(st + o_li, obs_li, (size_t)R * 4);
+  }
+  SFMX_HIP(c, hipMemcpyAsync(in, st, in_bytes, hipMemcpyHostToDevice, c->stream));
+  c->ba_upload_in_flight = true;  // cleared by the first build / step, which wait for the stream
   return SFMX_OK;
 }
 
@@ -785,6 +799,7 @@ int sfmx_ba_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, doubl
   SFMX_HIP(c, hipMemcpyAsync(S_out, q->S, (size_t)D * D * 8, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(b_out, q->b, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  c->ba_upload_in_flight = false;
   t.collect();
   return SFMX_OK;
 }
@@ -796,6 +811,7 @@ int sfmx_ba_build_partial(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_w
   int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, 0.0, 0, t);
   if (rc) return rc;
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  c->ba_upload_in_flight = false;
   t.collect();
   *S_dev = q->S;
   *b_dev = q->b;
@@ -816,6 +832,7 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
   SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 8));
   SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, q->work, (size_t)D * 8 + 4, hipMemcpyDeviceToHost, c->stream));  // dx | status
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  c->ba_upload_in_flight = false;
   t.collect();
   memcpy(dx_out, c->h[1].p, (size_t)D * 8);
   memcpy(&status, c->h[1].as<char>() + (size_t)D * 8, 4);
@@ -842,6 +859,7 @@ int sfmx_solve_dense(sfmx_ctx* c, const double* A, const double* b, int n, doubl
   SFMX_HIP(c, hipMemcpyAsync(x, c->d[2].p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipMemcpyAsync(&status, dstatus, 4, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  c->ba_upload_in_flight = false;
   t.collect();
   return status ? SFMX_ERR_SINGULAR : SFMX_OK;
 }
