@@ -71,8 +71,8 @@ def cpu_baseline(seq, cfg, sample_frames: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=47)
     ap.add_argument("--deg-per-frame", type=float, default=0.3)
     ap.add_argument("--max-tracks", type=int, default=2200)

@@ -15,8 +15,9 @@
 //      the reference's sequence (T:1015-1057): Hxx first, then the Schur term (which the reference
 //      ADDS, quirk Q6), bx then -G*bp for b; finally damping and gauge (T:1064-1071).  Coalesced
 //      loads run 16 points ahead of the dependent add chain, which is the only serial part.
-//  k_solve_gauss (one workgroup, matrix in LDS): partial-pivoting elimination with the reference's
-//      first-maximum pivot rule, row normalisation, |f| < 1e-18 skip and ascending back-substitution.
+//  k_solve_regs / k_solve_wave (one wavefront) and the blocked k_lu_* kernels (whole device): partial-pivoting
+//      elimination with the reference's first-maximum pivot rule, row normalisation, |f| < 1e-18 skip and ascending
+//      back-substitution.
 //
 // Algorithmic bytes per BA iteration: 20*R + 24*P + 96*W read, 8*(D^2+D) written.
 #include "sfmx_internal.h"
@@ -577,132 +578,298 @@ __global__ __launch_bounds__(64) void k_solve_regs(const double* __restrict__ Ai
   if (lane < N) x[lane] = xr;
 }
 
-// Larger systems: one 256-thread workgroup, matrix in LDS (n <= 141) or in a global working copy.
-template <bool IN_LDS>
-__global__ __launch_bounds__(256) void k_solve_gauss(const double* __restrict__ Ain, const double* __restrict__ bin, int n,
-                                                     double* __restrict__ x, int* __restrict__ status, double* __restrict__ gwork) {
-  extern __shared__ __align__(16) double sm[];
+// ------------------------------------------------------------------------------------------ blocked dense solve
+// Systems with more than 64 unknowns (the pose graph: 3 unknowns per keyframe): right-looking BLOCKED elimination over
+// the whole device.  Every matrix element still receives the reference's updates a_ij -= f_i(k) * r_kj(k) one pivot at
+// a time, in ascending k, with the same operands (separate multiply and subtract, no FMA) -- only the schedule changes:
+//   k_lu_panel   one workgroup factors LU_NB columns: pivot search (reference's first-maximum rule), row swaps inside the
+//                panel, division of the pivot row, update of the panel columns; the multipliers f_i(k) = a_ik stay in
+//                place of the entries the reference would overwrite with values it never reads again;
+//   k_lu_urow    one thread per trailing column (b rides along as column n): the panel's row swaps, then the LU_NB
+//                pivot rows of the block, each normalised by its saved pivot and applied to the block rows below it;
+//   k_lu_update  all trailing rows x columns: the LU_NB delayed updates of each element, in order, from LDS tiles;
+//   k_lu_backsub one workgroup: the reference's ascending-j subtraction chain per row (strictly serial by its order),
+//                fed with products A(i,j)*x[j] that all rows form as soon as x[j] exists.
+// The |f| < 1e-18 skip (dense.hpp:80) is re-evaluated from the stored multiplier wherever it is applied.
+#define LU_NB 32
+__global__ void k_lu_init(const double* __restrict__ A, const double* __restrict__ b, int n, double* __restrict__ Wm, int* __restrict__ status) {
   const int ld = n + 1;
-  double* A;
-  if constexpr (IN_LDS) A = sm; else A = gwork;
-  double* bb = A + (size_t)n * ld;
-  double* fcol = bb + n;
-  __shared__ double red_v[4];
-  __shared__ int red_i[4];
-  __shared__ int s_piv, s_stop;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  for (int e = tid; e < n * n; e += nt) A[(size_t)(e / n) * ld + (e % n)] = Ain[e];
-  for (int e = tid; e < n; e += nt) bb[e] = bin[e];
-  if (tid == 0) s_stop = 0;
+  const size_t total = (size_t)n * ld;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / ld), j = (int)(e % ld);
+    Wm[e] = j < n ? A[(size_t)i * n + j] : b[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) status[0] = 0;
+}
+
+// The panel is worked on in a COLUMN-major copy Pn[LU_NB][m] (m = n - k0 rows): the pivot search and the row-parallel
+// updates then touch consecutive addresses.  IN_LDS: the copy lives in LDS (m * LU_NB doubles <= 128 KiB), otherwise in
+// a global scratch area.
+#define LU_PANEL_THREADS 256
+template <bool IN_LDS>
+__global__ __launch_bounds__(LU_PANEL_THREADS) void k_lu_panel(double* __restrict__ Wm, int n, int k0, int* __restrict__ piv_out,
+                                                               double* __restrict__ akk_out, int* __restrict__ status,
+                                                               double* __restrict__ gscratch) {
+  extern __shared__ __align__(16) double lds_panel[];
+  __shared__ double rrow[LU_NB];
+  __shared__ double red_v[2][LU_PANEL_THREADS / 64];
+  __shared__ int red_i[2][LU_PANEL_THREADS / 64];
+  if (status[0]) return;
+  const int ld = n + 1, tid = threadIdx.x, nt = blockDim.x;
+  const int k1 = min(k0 + LU_NB, n), nbr = k1 - k0, m = n - k0;
+  double* Pn;
+  if constexpr (IN_LDS) Pn = lds_panel; else Pn = gscratch;
+  for (int e = tid; e < m * nbr; e += nt) {  // e = r * nbr + c: each row's panel entries are contiguous in Wm
+    const int r = e / nbr, c = e % nbr;
+    Pn[(size_t)c * m + r] = Wm[(size_t)(k0 + r) * ld + k0 + c];
+  }
   __syncthreads();
-  for (int k = 0; k < n; k++) {
-    double bv = -1.0;
-    int bi = 0x7fffffff;
-    for (int i = k + tid; i < n; i += nt) {
-      const double v = fabs(A[(size_t)i * ld + k]);
-      if (v > bv) { bv = v; bi = i; }
-    }
+  // pivot candidates of step 0; later steps get theirs from the update loop of the step before
+  double bv = -1.0;
+  int bi = 0x7fffffff;
+  for (int r = tid; r < m; r += nt) {
+    const double v = fabs(Pn[r]);
+    if (v > bv) { bv = v; bi = r; }  // NaN never wins `v > best`
+  }
+  for (int kk = 0; kk < nbr; kk++) {
+    const int k = k0 + kk;
+    double* colk = Pn + (size_t)kk * m;
+    // ---- pivot (dense.hpp:61-67): first maximum of |a_ik| over rows i >= k; every thread finishes the reduction itself
     for (int o = 32; o > 0; o >>= 1) {
       const double ov = __shfl_down(bv, o, 64);
       const int oi = __shfl_down(bi, o, 64);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+    const int par = kk & 1;  // double-buffered so that one barrier per reduction suffices
+    if ((tid & 63) == 0) { red_v[par][tid >> 6] = bv; red_i[par][tid >> 6] = bi; }
     __syncthreads();
-    if (tid == 0) {
-      double v = red_v[0];
-      int ix = red_i[0];
-      for (int w = 1; w < (nt >> 6); w++)
-        if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
-      const double akk0 = fabs(A[(size_t)k * ld + k]);
-      int piv = ix;
-      double best = v;
-      if (akk0 != akk0) { piv = k; best = akk0; }
-      else if (piv == 0x7fffffff) { piv = k; best = akk0; }
-      s_piv = piv;
-      if (best < 1e-15) s_stop = 1;
-    }
-    __syncthreads();
-    if (s_stop) {
+    double v = red_v[par][0];
+    int piv = red_i[par][0];
+#pragma unroll
+    for (int w = 1; w < LU_PANEL_THREADS / 64; w++)
+      if (red_v[par][w] > v || (red_v[par][w] == v && red_i[par][w] < piv)) { v = red_v[par][w]; piv = red_i[par][w]; }
+    const double akk0 = fabs(colk[kk]);
+    double best = v;
+    if (akk0 != akk0) { piv = kk; best = akk0; }  // a NaN on the diagonal stays the pivot
+    else if (piv == 0x7fffffff) { piv = kk; best = akk0; }
+    if (best < 1e-15) {  // uniform: every thread evaluated the same data
       if (tid == 0) status[0] = 1;
       return;
     }
-    const int piv = s_piv;
-    if (piv != k) {
-      for (int j = k + tid; j < n; j += nt) {
-        const double t = A[(size_t)k * ld + j];
-        A[(size_t)k * ld + j] = A[(size_t)piv * ld + j];
-        A[(size_t)piv * ld + j] = t;
+    const double akk = colk[piv];  // A(k,k) after the swap (dense.hpp:74)
+    if (tid == 0) { piv_out[k] = k0 + piv; akk_out[k] = akk; }
+    __syncthreads();  // everybody has read column k before the swap rewrites it
+    // ---- row swap inside the panel (all its columns: the multipliers of earlier panel steps travel with their row)
+    // fused with the normalisation of the pivot row (dense.hpp:69-75): thread c owns column c
+    if (tid < nbr) {
+      double* cj = Pn + (size_t)tid * m;
+      const double top = cj[kk], low = cj[piv];
+      const double newk = tid >= kk ? low / akk : low;
+      cj[kk] = newk;
+      if (piv != kk) cj[piv] = top;
+      rrow[tid] = newk;
+    }
+    __syncthreads();
+    // ---- update the panel columns right of k (dense.hpp:78-82); column k keeps the multiplier.  The next step's
+    // pivot candidates (column kk+1, rows > kk) are taken from the values just written.
+    bv = -1.0;
+    bi = 0x7fffffff;
+    double* cnext = Pn + (size_t)(kk + 1) * m;
+    for (int r = kk + 1 + tid; r < m; r += nt) {
+      const double f = colk[r];
+      if (!(fabs(f) < 1e-18)) {
+        for (int c = kk + 1; c < nbr; c++) {
+          double* cc = Pn + (size_t)c * m;
+          cc[r] = cc[r] - f * rrow[c];
+        }
       }
-      if (tid == 0) { const double t = bb[k]; bb[k] = bb[piv]; bb[piv] = t; }
-    }
-    __syncthreads();
-    const double akk = A[(size_t)k * ld + k];
-    __syncthreads();
-    for (int j = k + tid; j < n; j += nt) A[(size_t)k * ld + j] /= akk;
-    if (tid == 0) bb[k] /= akk;
-    for (int i = k + 1 + tid; i < n; i += nt) fcol[i] = A[(size_t)i * ld + k];
-    __syncthreads();
-    const int cols = n - k, rows = n - k - 1;
-    for (int e = tid; e < rows * cols; e += nt) {
-      const int i = k + 1 + e / cols, j = k + e % cols;
-      const double f = fcol[i];
-      if (fabs(f) < 1e-18) continue;
-      A[(size_t)i * ld + j] -= f * A[(size_t)k * ld + j];
-    }
-    for (int i = k + 1 + tid; i < n; i += nt) {
-      const double f = fcol[i];
-      if (fabs(f) < 1e-18) continue;
-      bb[i] -= f * bb[k];
-    }
-    __syncthreads();
-  }
-  for (int j = n - 1; j >= 0; j--) {
-    if (tid == 0) {
-      double sacc = bb[j];
-      const double* row = A + (size_t)j * ld;
-      int c = j + 1;
-      for (; c + 8 <= n; c += 8) {
-        const double p0 = row[c], p1 = row[c + 1], p2 = row[c + 2], p3 = row[c + 3], p4 = row[c + 4], p5 = row[c + 5], p6 = row[c + 6],
-                     p7 = row[c + 7];
-        sacc -= p0; sacc -= p1; sacc -= p2; sacc -= p3; sacc -= p4; sacc -= p5; sacc -= p6; sacc -= p7;
+      if (kk + 1 < nbr) {
+        const double vv = fabs(cnext[r]);
+        if (vv > bv) { bv = vv; bi = r; }
       }
-      for (; c < n; c++) sacc -= row[c];
-      fcol[j] = sacc;
     }
-    __syncthreads();
-    const double xj = fcol[j];
-    for (int i = tid; i < j; i += nt) A[(size_t)i * ld + j] = A[(size_t)i * ld + j] * xj;
-    __syncthreads();
+    // (no barrier here: the next reduction's barrier orders these writes before any cross-thread read)
   }
-  if (tid == 0) status[0] = 0;
-  for (int e = tid; e < n; e += nt) x[e] = fcol[e];
+  __syncthreads();
+  for (int e = tid; e < m * nbr; e += nt) {
+    const int r = e / nbr, c = e % nbr;
+    Wm[(size_t)(k0 + r) * ld + k0 + c] = Pn[(size_t)c * m + r];
+  }
 }
 
-static size_t solve_shmem(int n) { return ((size_t)n * (n + 1) + 2 * (size_t)n) * sizeof(double); }
-#define SOLVE_LDS_MAX_N 141   // 141*142*8 + 2*141*8 + statics < 160 KiB
-#define SOLVE_MAX_N 4096
-
-// n <= 64: wave-synchronous kernel.  n <= 141: block kernel, system in LDS.  Larger systems (pose
-// graphs): same block kernel on a global working copy in ctx->d[7] -- correct and reference-ordered,
-// single workgroup (the blocked multi-CU solver for D ~ 1e4 is a "next" row).
-static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    SFMX_HIP(c, hipFuncSetAttribute((const void*)k_solve_gauss<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_shmem(SOLVE_LDS_MAX_N)));
-    attr_set = true;
+__global__ __launch_bounds__(256) void k_lu_urow(double* __restrict__ Wm, int n, int k0, const int* __restrict__ piv, const double* __restrict__ akk,
+                                                 const int* __restrict__ status) {
+  __shared__ double Lb[LU_NB][LU_NB + 1];  // multipliers of the block rows: Lb[ii][kk] = a(k0+ii, k0+kk), kk < ii
+  __shared__ double pv[LU_NB];
+  __shared__ int src_blk[LU_NB];           // row whose content ends up in block row kk after the panel's swaps
+  __shared__ int out_row[LU_NB], out_src[LU_NB], n_out;  // rows below the block that receive other content
+  __shared__ int pos[2 * LU_NB], cur[2 * LU_NB];
+  if (status[0]) return;
+  const int ld = n + 1, k1 = min(k0 + LU_NB, n), nbr = k1 - k0;
+  for (int e = threadIdx.x; e < LU_NB * LU_NB; e += blockDim.x) {
+    const int ii = e / LU_NB, kk = e % LU_NB;
+    Lb[ii][kk] = (ii < nbr && kk < nbr) ? Wm[(size_t)(k0 + ii) * ld + k0 + kk] : 0.0;
   }
+  if (threadIdx.x < LU_NB) pv[threadIdx.x] = threadIdx.x < nbr ? akk[k0 + threadIdx.x] : 1.0;
+  if (threadIdx.x == 0) {
+    // the swaps (dense.hpp:69-72) as one permutation: cur[q] = original row now sitting at tracked position q
+    int np_ = 0;  // pos / cur live in LDS: dynamically indexed private arrays would go to scratch memory
+    for (int kk = 0; kk < nbr; kk++) { pos[np_] = k0 + kk; cur[np_] = k0 + kk; np_++; }
+    for (int kk = 0; kk < nbr; kk++) {
+      const int p = piv[k0 + kk];
+      if (p == k0 + kk) continue;
+      int q = -1;
+      for (int s = 0; s < np_; s++)
+        if (pos[s] == p) q = s;
+      if (q < 0) { q = np_; pos[np_] = p; cur[np_] = p; np_++; }
+      const int tmp = cur[kk];
+      cur[kk] = cur[q];
+      cur[q] = tmp;
+    }
+    int no = 0;
+    for (int s = 0; s < np_; s++) {
+      if (s < nbr) src_blk[s] = cur[s];
+      else if (cur[s] != pos[s]) { out_row[no] = pos[s]; out_src[no] = cur[s]; no++; }
+    }
+    n_out = no;
+  }
+  __syncthreads();
+  const int j = k1 + blockIdx.x * blockDim.x + threadIdx.x;  // trailing column, n = the right-hand side
+  if (j > n) return;
+  // all loads first (independent), then the stores: sources and destinations are the same set of rows
+  double col[LU_NB], spill[LU_NB];
+  const int no = n_out;
+#pragma unroll
+  for (int kk = 0; kk < LU_NB; kk++) col[kk] = kk < nbr ? Wm[(size_t)src_blk[kk] * ld + j] : 0.0;
+#pragma unroll
+  for (int s = 0; s < LU_NB; s++) spill[s] = s < no ? Wm[(size_t)out_src[s] * ld + j] : 0.0;
+#pragma unroll
+  for (int s = 0; s < LU_NB; s++)
+    if (s < no) Wm[(size_t)out_row[s] * ld + j] = spill[s];
+#pragma unroll
+  for (int kk = 0; kk < LU_NB; kk++) {
+    if (kk < nbr) {
+      const double r = col[kk] / pv[kk];  // dense.hpp:75-76
+      col[kk] = r;
+#pragma unroll
+      for (int ii = kk + 1; ii < LU_NB; ii++) {
+        const double f = Lb[ii][kk];
+        if (ii < nbr && !(fabs(f) < 1e-18)) col[ii] = col[ii] - f * r;  // dense.hpp:79-83
+      }
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < LU_NB; kk++)
+    if (kk < nbr) Wm[(size_t)(k0 + kk) * ld + j] = col[kk];
+}
+
+#define LU_TILE 16
+__global__ __launch_bounds__(LU_TILE* LU_TILE) void k_lu_update(double* __restrict__ Wm, int n, int k0, const int* __restrict__ status) {
+  __shared__ double Lt[LU_TILE][LU_NB + 1];  // multipliers of this tile's rows
+  __shared__ double Ut[LU_NB][LU_TILE + 1];  // normalised pivot rows of this tile's columns
+  if (status[0]) return;
+  const int ld = n + 1, k1 = min(k0 + LU_NB, n), nbr = k1 - k0;
+  const int tx = threadIdx.x % LU_TILE, ty = threadIdx.x / LU_TILE;
+  const int i0 = k1 + blockIdx.y * LU_TILE, j0 = k1 + blockIdx.x * LU_TILE;
+  for (int e = threadIdx.x; e < LU_TILE * LU_NB; e += LU_TILE * LU_TILE) {
+    const int r = e / LU_NB, kk = e % LU_NB;
+    Lt[r][kk] = (i0 + r < n && kk < nbr) ? Wm[(size_t)(i0 + r) * ld + k0 + kk] : 0.0;
+  }
+  for (int e = threadIdx.x; e < LU_NB * LU_TILE; e += LU_TILE * LU_TILE) {
+    const int kk = e / LU_TILE, c = e % LU_TILE;
+    Ut[kk][c] = (j0 + c <= n && kk < nbr) ? Wm[(size_t)(k0 + kk) * ld + j0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int i = i0 + ty, j = j0 + tx;
+  if (i >= n || j > n) return;
+  double acc = Wm[(size_t)i * ld + j];
+#pragma unroll 8
+  for (int kk = 0; kk < nbr; kk++) {
+    const double f = Lt[ty][kk];
+    if (!(fabs(f) < 1e-18)) acc = acc - f * Ut[kk][tx];  // dense.hpp:79-83, pivots k0+kk in ascending order
+  }
+  Wm[(size_t)i * ld + j] = acc;
+}
+
+// back-substitution (dense.hpp:86-91) on the eliminated system; unit diagonal.  The subtraction chain of row i is
+// strictly serial and can only start when x[i+1] exists, so everything else is taken off that path: while thread 0
+// runs the chain of row i out of LDS, the other threads stage row i-1 -- the products A(i-1,j)*x[j] for the columns
+// whose x is known (x lives in LDS), the raw A(i-1,i) for the one that is not; thread 0 forms that last product itself.
+__global__ __launch_bounds__(512) void k_lu_backsub(const double* __restrict__ Wm, int n, double* __restrict__ x, int* __restrict__ status) {
+  extern __shared__ __align__(16) double bs_lds[];  // x[n] | row buffers [2][n]
+  if (status[0]) return;
+  double* xs = bs_lds;
+  const int ld = n + 1, tid = threadIdx.x, nt = blockDim.x;
+  for (int i = n - 1; i >= 0; i--) {
+    double* cur = bs_lds + (size_t)n * (1 + (i & 1));        // row i: staged one iteration ago
+    double* nxt = bs_lds + (size_t)n * (1 + ((i + 1) & 1));  // row i-1
+    if (tid == 0) {
+      double s = Wm[(size_t)i * ld + n];
+      if (i + 1 < n) {
+        s -= cur[i + 1] * xs[i + 1];  // the newest product (dense.hpp:89)
+        int c = i + 2;
+        for (; c + 16 <= n; c += 16) {
+          double p[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) p[q] = cur[c + q];
+#pragma unroll
+          for (int q = 0; q < 16; q++) s -= p[q];
+        }
+        for (; c < n; c++) s -= cur[c];
+      }
+      xs[i] = s;
+      x[i] = s;
+    } else if (i >= 1) {
+      const double* rowm = Wm + (size_t)(i - 1) * ld;
+      for (int c = i + (tid - 1); c < n; c += nt - 1) {
+        const double v = rowm[c];
+        nxt[c] = (c == i) ? v : v * xs[c];  // xs[c], c > i, was written in an earlier iteration
+      }
+    }
+    __syncthreads();
+  }
+}
+
+#define SOLVE_MAX_N 6400  // back-substitution keeps x and two staged rows in LDS: 3 * n * 8 <= 156 KiB
+
+// n == 36 / 60: rows in registers.  n <= 64: wave-synchronous LDS kernel.  Larger systems (pose graphs): blocked
+// elimination over the whole device on a working copy [n][n+1] in ctx->d[7].
+static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
   if (n == 36) {  // window of 6 (the reference default) and of 10 (C4): rows in registers
     k_solve_regs<36><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus);
   } else if (n == 60) {
     k_solve_regs<60><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus);
   } else if (n <= SOLVE_WAVE_MAX_N) {
     k_solve_wave<<<1, 64, 0, c->stream>>>(dA, db, n, dx, dstatus);
-  } else if (n <= SOLVE_LDS_MAX_N) {
-    k_solve_gauss<true><<<1, 256, solve_shmem(n), c->stream>>>(dA, db, n, dx, dstatus, nullptr);
   } else {
-    SFMX_HIP(c, c->d[7].ensure(solve_shmem(n)));
-    k_solve_gauss<false><<<1, 256, 0, c->stream>>>(dA, db, n, dx, dstatus, c->d[7].as<double>());
+    const size_t wbytes = (size_t)n * (n + 1) * 8, abytes = (size_t)n * 8, pbytes = (((size_t)n * 4) + 15) & ~(size_t)15;
+    const size_t sbytes = (size_t)n * LU_NB * 8;  // column-major panel copy when it does not fit in LDS
+    SFMX_HIP(c, c->d[7].ensure(wbytes + abytes + pbytes + sbytes + 64));
+    double* Wm = c->d[7].as<double>();
+    double* akk = reinterpret_cast<double*>(c->d[7].as<char>() + wbytes);
+    int* piv = reinterpret_cast<int*>(c->d[7].as<char>() + wbytes + abytes);
+    double* scratch = reinterpret_cast<double*>(c->d[7].as<char>() + wbytes + abytes + pbytes);
+    constexpr size_t kPanelLds = 156 * 1024;  // 160 KiB of LDS per workgroup minus the kernel's static arrays
+    static bool attr_set = false;
+    if (!attr_set) {
+      SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
+      SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
+      attr_set = true;
+    }
+    k_lu_init<<<256, 256, 0, c->stream>>>(dA, db, n, Wm, dstatus);
+    for (int k0 = 0; k0 < n; k0 += LU_NB) {
+      const int k1 = k0 + LU_NB < n ? k0 + LU_NB : n;
+      const size_t pan = (size_t)(n - k0) * LU_NB * 8;
+      if (pan <= kPanelLds) k_lu_panel<true><<<1, LU_PANEL_THREADS, pan, c->stream>>>(Wm, n, k0, piv, akk, dstatus, nullptr);
+      else k_lu_panel<false><<<1, LU_PANEL_THREADS, 0, c->stream>>>(Wm, n, k0, piv, akk, dstatus, scratch);
+      const int tcols = n - k1 + 1;  // trailing columns incl. the right-hand side
+      k_lu_urow<<<(tcols + 255) / 256, 256, 0, c->stream>>>(Wm, n, k0, piv, akk, dstatus);
+      if (k1 < n) {
+        const dim3 grid((tcols + LU_TILE - 1) / LU_TILE, (n - k1 + LU_TILE - 1) / LU_TILE);
+        k_lu_update<<<grid, LU_TILE * LU_TILE, 0, c->stream>>>(Wm, n, k0, dstatus);
+      }
+    }
+    k_lu_backsub<<<1, 512, (size_t)3 * n * 8, c->stream>>>(Wm, n, dx, dstatus);
   }
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;
@@ -841,7 +1008,7 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
 
 int sfmx_solve_dense(sfmx_ctx* c, const double* A, const double* b, int n, double* x) {
   SFMX_REQUIRE(c, c && A && b && x && n >= 1);
-  if (n > SOLVE_MAX_N) return sfmx_fail(c, SFMX_ERR_UNSUPPORTED, "sfmx_solve_dense: n > 4096 (single-workgroup solver)", hipSuccess);
+  if (n > SOLVE_MAX_N) return sfmx_fail(c, SFMX_ERR_UNSUPPORTED, "sfmx_solve_dense: n > 6400", hipSuccess);
   const size_t nb = (size_t)n * n * 8;
   c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(nb));

@@ -1122,6 +1122,14 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   FrameFeeder feeder(ctx, src, cfg.klt, dlevel + 1, dlevel, n_frames, track_lane, prefetch.get(), prefetch_workers + 1, &clk);
   CornerDetector geo_det(ctx, &clk);                                  // loop closure: corners of old keyframe images ...
   std::unordered_map<int, std::shared_ptr<const CornerMemo>> kf_corners;  // ... unless their sequence is already known
+  // only the first `loop_corners` corners of a keyframe image are ever asked for again (T:1838-1841): keep that prefix
+  const int loop_corners = 1200;
+  auto keep_corners = [&](int frame, const std::shared_ptr<const CornerMemo>& m) {
+    if (!m) return;
+    if ((int)m->corners.size() <= loop_corners) { kf_corners[frame] = m; return; }
+    CornerMemo cut{m->quality, m->min_dist, std::min(m->cap, loop_corners), false, m->prefix(loop_corners)};
+    kf_corners[frame] = std::make_shared<const CornerMemo>(std::move(cut));
+  };
   // Lane B: the keyframe->keyframe RANSAC (its edge only feeds the pose graph / CSV) and the local BA of keyframe k
   // do not feed frame k+1's tracking or frame->frame RANSAC, so they run on a second context while the main
   // thread goes on; they are joined before the next keyframe is built (triangulation reads the refined poses)
@@ -1234,7 +1242,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       kf.img_name = meta[(size_t)fi].name;
       kf.pose = cur;
       kf_desc.push_back(pkt.desc);
-      if (pkt.corners) kf_corners[fi] = pkt.corners;
+      keep_corners(fi, pkt.corners);
       for (const Track& tr : pkt.tracks) {
         kf.obs.emplace(tr.id, tr.p);
         track_hist[tr.id].obs.push_back({kf.kf_id, tr.p});
@@ -1281,7 +1289,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       kf.img_name = meta[(size_t)fi].name;
       kf.pose = cur;
       const std::vector<float>& new_desc = pkt.desc;
-      if (pkt.corners) kf_corners[fi] = pkt.corners;
+      keep_corners(fi, pkt.corners);
       const auto tb0 = Clock::now();
       for (const Track& tr : pkt.tracks) {
         kf.obs.emplace(tr.id, tr.p);
@@ -1371,7 +1379,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       if (best_id >= 0 && best_score > 0.94f) {
         const Keyframe& old_kf = kfs[(size_t)best_id];
         LKConfig lc = cfg.klt;
-        lc.max_tracks = 1200;
+        lc.max_tracks = loop_corners;
         lc.min_tracks = 600;
         // corners of the old keyframe image (T:1841): a prefix of the sequence found when that frame was current (same
         // image, quality, min_dist); detected here only if the tracker never replenished on that frame

@@ -290,6 +290,56 @@ def test_solve_dense(ctx, golden):
     H.assert_bits_equal(x, ex, "nan solve", nan_equal=True)
 
 
+def test_solve_dense_blocked_sizes(ctx):
+    """n > 64 takes the blocked multi-workgroup elimination (pose graphs: 3 unknowns per keyframe).  Bit-exact against the
+    oracle's solve_gauss on sizes around the block edges, on a pose-graph-shaped system, with tied pivots, skipped
+    multipliers, NaN and a singular matrix deep inside."""
+    rng = np.random.default_rng(21)
+    for n in (65, 96, 97, 141, 300, 513):
+        A = rng.normal(size=(n, n))
+        b = rng.normal(size=n)
+        if n == 97:
+            A[40, :] *= 1e-20          # |f| < 1e-18 skip in the panel, in the block rows and in the trailing update
+            A[:, 70] *= 1e-21
+        if n == 141:
+            A[100] = A[20]             # duplicate rows: tied pivot candidates, later an exactly singular step
+        if n == 300:
+            A = np.round(A * 4) / 4    # many exactly equal |a_ik|: first-maximum rule
+        rc, x = ctx.solve_dense(A, b)
+        erc, ex = H.solve_gauss(O, "orc", A, b)
+        assert (rc != 0) == (erc != 0), n
+        if rc == 0:
+            H.assert_bits_equal(x, ex, f"blocked n={n}")
+    # pose-graph shape: weighted graph Laplacian (x) I3 plus a gauge term, 100 keyframes -> 300 unknowns
+    N = 100
+    L = np.zeros((3 * N, 3 * N))
+    for a in range(N - 1):
+        for c, w in ((a + 1, 400.0 + a), (min(N - 1, a + 7), 90.0)):
+            for d in range(3):
+                L[3 * a + d, 3 * a + d] += w; L[3 * c + d, 3 * c + d] += w
+                L[3 * a + d, 3 * c + d] -= w; L[3 * c + d, 3 * a + d] -= w
+    L[:3, :3] += np.eye(3) * 1e9
+    g = rng.normal(size=3 * N)
+    rc, x = ctx.solve_dense(L, g)
+    erc, ex = H.solve_gauss(O, "orc", L, g)
+    assert rc == erc == 0
+    H.assert_bits_equal(x, ex, "pose-graph system")
+    A = rng.normal(size=(130, 130))
+    A[77, 3] = np.nan
+    rc, x = ctx.solve_dense(A, np.ones(130))
+    erc, ex = H.solve_gauss(O, "orc", A, np.ones(130))
+    assert rc == erc
+    if rc == 0:
+        H.assert_bits_equal(x, ex, "nan blocked", nan_equal=True)
+    A = rng.normal(size=(200, 200))
+    A[:, 150] = A[:, 10] * 2.0     # rank deficient: the pivot of some step deep inside falls below 1e-15 (or rounding keeps it alive -- same verdict either way)
+    rc, x = ctx.solve_dense(A, np.ones(200))
+    erc, ex = H.solve_gauss(O, "orc", A, np.ones(200))
+    assert (rc != 0) == (erc != 0)
+    if rc == 0:
+        H.assert_bits_equal(x, ex, "rank-deficient blocked", nan_equal=True)
+
+
 def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
     """dist.ba_step_sharded (partial build -> [all-reduce] -> damp/gauge -> solve) on one rank must equal the fused
     sfmx_ba_step bit for bit: same sums, no collective reordering with world size 1."""

@@ -12,7 +12,7 @@ def med(f, n=7):
         f(); v.append(ctx.last_kernel_us())
     return float(np.median(v)), float(np.min(v))
 rng = np.random.default_rng(0)
-for n in (12, 36, 60, 141):
+for n in (12, 36, 60, 141, 300, 600):
     M = rng.normal(size=(n, n)); A = M @ M.T + np.eye(n) * 1e-3; b = rng.normal(size=n)
     print(f"solve n={n}: med/min us", med(lambda: ctx.solve_dense(A, b)))
 seq = synth.make_sequence(2, 640, 480, 0.3, n_blobs=20000, seed=7)
