@@ -123,8 +123,13 @@ def main():
     t0 = time.perf_counter()
     kf_total = 0
     last = None
+    identical = True  # five host lanes reorder WHEN work happens, never WHAT comes out: every pass must agree bit for bit
     for _ in range(args.steps):
-        last = one_pass()
+        cur_pass = one_pass()
+        if last is not None:
+            identical = identical and cur_pass["log"] == last["log"] and np.array_equal(
+                cur_pass["centres"].view(np.uint64), last["centres"].view(np.uint64))
+        last = cur_pass
         kf_total += last["stats"]["n_keyframes"]
     ctx.sync()
     barrier()
@@ -211,7 +216,7 @@ def main():
                                    f"reference default config (max_tracks={args.max_tracks}, RANSAC 2500 iters, BA window 6 / 600 pts / 5 iters); "
                                    "one independent sequence per GPU", "frames_per_step": args.frames, "parallelism": f"sequences x{world}"},
             "frames_per_s": round(args.frames * args.steps * world / dt, 2),
-            "keyframes_per_step": st["n_keyframes"], "map_points": st["n_points"],
+            "keyframes_per_step": st["n_keyframes"], "map_points": st["n_points"], "passes_bit_identical": bool(identical),
             "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_wall", "sec_total", "sec_setup", "sec_klt", "sec_shi", "sec_shi_wait", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_pf_busy", "sec_pf_gpu", "sec_pf_replay", "sec_lane_b_busy", "sec_lane_c_busy", "sec_join_wait", "sec_ba_gather", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_feed_wait")},
             "counters_per_step": {k: int(st[k]) for k in ("klt_calls", "tracks_in", "lk_steps", "ransac_calls", "ransac_points", "ransac_verified", "ba_calls", "ba_iters", "shi_calls", "shi_memo_hits", "shi_prefetched", "shi_fallbacks")},
             "roofline": roofline,

@@ -1130,12 +1130,13 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     CornerMemo cut{m->quality, m->min_dist, std::min(m->cap, loop_corners), false, m->prefix(loop_corners)};
     kf_corners[frame] = std::make_shared<const CornerMemo>(std::move(cut));
   };
-  // Lane B: the keyframe->keyframe RANSAC (its edge only feeds the pose graph / CSV) and the local BA of keyframe k
-  // do not feed frame k+1's tracking or frame->frame RANSAC, so they run on a second context while the main
-  // thread goes on; they are joined before the next keyframe is built (triangulation reads the refined poses)
-  // and before any pose-graph use.  SFMX_NO_ASYNC=1 runs everything on the main lane.
-  // Lane C takes the loop-closure verification of keyframe k (KLT old-keyframe -> new-keyframe + RANSAC, T:1834-1858):
-  // its verdict is only consumed -- pose graph + second BA, T:1859-1863 -- before the next keyframe is built.
+  // Lane B: the local BA of keyframe k (T:1820) does not feed frame k+1's tracking or frame->frame RANSAC, so its device
+  // iterations run on a second context while this thread goes on; it is joined right before the next keyframe's
+  // triangulation reads the refined poses, and before any pose-graph use.
+  // Lane C: the keyframe->keyframe RANSAC (T:1793; its edge only feeds the pose graph / CSV) and the loop-closure
+  // verification of keyframe k (KLT old-keyframe -> new-keyframe + RANSAC, T:1834-1858), whose verdict is only consumed
+  // -- pose graph + second BA, T:1859-1863 -- before the next keyframe is built.
+  // SFMX_NO_ASYNC=1 runs everything on this thread.
   const bool use_lane = !std::getenv("SFMX_NO_ASYNC");
   StageClock lane_clk, lane_c_clk;
   std::unique_ptr<AsyncLane> lane, lane_c;
@@ -1172,7 +1173,6 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   std::vector<Keyframe>& kfs = out.kfs;
   MapState& map = out.map;
   std::vector<PGEdge>& edges = out.edges;
-  // wait for lane B and fold its results in, in submission order (odometry edge of keyframe k, then BA(k))
   // Joining is split so that the wait for BA(k) can be pushed as late as the data dependence allows:
   //   join_c: lane C is done -> append its edge(s); returns true if the loop closure of keyframe k was accepted
   //   join_b: lane B is done -> write BA(k)'s poses back
