@@ -597,8 +597,12 @@ void sfmx_release_graphs(sfmx_ctx* c) {
     }
 }
 #define SHI_SPEC 4096
+#ifndef SHI_TILED_SWEEPS
 #define SHI_TILED_SWEEPS 5
+#endif
+#ifndef SHI_LIST_SWEEPS
 #define SHI_LIST_SWEEPS 8
+#endif
 #define SHI_TAIL_SWEEPS 40
 
 static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap) {
