@@ -125,6 +125,28 @@ def test_cli_drop_in(tmp_path):
     assert q.returncode == 0 and q.stdout.count("frame ") == 3
 
 
+def test_long_sequence_lanes_equal_serial(ctx, tmp_path, monkeypatch):
+    """120 frames (every one a keyframe, loop closures being verified all along): the five-lane schedule, run twice, and
+    the fully serial one must write the same bytes -- the short CLI sequences above hardly fill the tracker lane's ring."""
+    seq = synth.make_sequence(120, 320, 240, 0.3, n_blobs=12000, seed=5)
+    cfg = dict(H.PIPE_DEFAULTS, frames=120, max_tracks=900, min_tracks=400, kf_min_inliers=100000)  # inliers < kf_min_inliers: keyframe (T:1700-1704)
+    outs = []
+    for k, serial in enumerate((False, True, False)):
+        if serial:
+            monkeypatch.setenv("SFMX_NO_ASYNC", "1")
+            monkeypatch.setenv("SFMX_NO_PREFETCH", "1")
+        else:
+            monkeypatch.delenv("SFMX_NO_ASYNC", raising=False)
+            monkeypatch.delenv("SFMX_NO_PREFETCH", raising=False)
+        out = str(tmp_path / f"o{k}")
+        r = pipe.run(ctx, seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out)
+        outs.append((r["log"].replace(out, "X"), out, r["stats"]))
+    assert outs[0][2]["n_keyframes"] >= 100 and outs[0][2]["n_points"] > 1000
+    for k in (1, 2):
+        assert outs[0][0] == outs[k][0]
+        _same_files(outs[0][1], outs[k][1])
+
+
 def test_shi_fast_path_equals_full_sort(tmp_path):
     """The prefix-select fast path of the corner pick must equal the full std::sort path (run in a
     child process with SFMX_SHI_FULL_SORT=1) byte for byte, on a noisy and on a noise-free (tie-prone) scene."""
