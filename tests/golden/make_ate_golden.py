@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as H
 synth = importlib.import_module(H.PKG_NAME + ".synth")
 REF = os.path.join(ROOT, "oracle", "_ref", "ate_keyframes_ref")
+REF2 = os.path.join(ROOT, "oracle", "_ref", "ate_two_frames_ref")
 
 
 def par_text(seq):
@@ -71,6 +72,48 @@ def main():
             out["cases"].append({"args": args, "rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr})
             print(args, "->", r.returncode, r.stdout.count("\n"), "lines")
     json.dump(out, open(os.path.join(HERE, "ate_keyframes.json"), "w"), indent=1)
+
+    # ---- ate_two_frames: closed-form two-point alignment
+    gt0, gt1 = C[0], C[1]
+    d = gt1 - gt0
+    files2 = {
+        "par.txt": files["par.txt"],
+        "par_short.txt": files["par.txt"] + "broken.png 1 2 3\n",                       # a short record spoils the file
+        "kf.csv": files["kf.csv"],
+        "kf_same_dir.csv": csv([gt0 * 1.0, gt0 + 2.5 * d] + list(est[2:]), seq["names"]),   # parallel baselines: identity rotation
+        "kf_opposite.csv": csv([gt0 * 1.0, gt0 - 0.7 * d] + list(est[2:]), seq["names"]),   # anti-parallel: half turn
+        "kf_zero.csv": csv([est[0], est[0]] + list(est[2:]), seq["names"]),                # zero estimated baseline
+        "kf_ragged.csv": csv(est, seq["names"], extra_rows=["1,2", "7,7,templeR0003.png,1,2,3", "8,8,templeR0004.png,1,2,3,0,0,extra"]),
+        "kf_unknown.csv": files["kf_unknown.csv"],
+        "kf_nocol.csv": files["kf_nocol.csv"],
+    }
+    cases2 = [
+        ["--par", "par.txt", "--keyframes", "kf.csv"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "3", "--j", "11"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "9", "--j", "2", "--se3"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--se3", "--sim3", "--i", "x", "--j", "5"],
+        ["--par", "par.txt", "--keyframes", "kf_same_dir.csv"],
+        ["--par", "par.txt", "--keyframes", "kf_opposite.csv"],
+        ["--par", "par.txt", "--keyframes", "kf_zero.csv"],
+        ["--par", "par.txt", "--keyframes", "kf_zero.csv", "--se3"],
+        ["--par", "par.txt", "--keyframes", "kf_ragged.csv", "--i", "16", "--j", "17"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "2", "--j", "2"],            # invalid indices
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--j", "40"],                        # out of range
+        ["--par", "par.txt", "--keyframes", "kf_unknown.csv"],                             # name missing in par
+        ["--par", "par_short.txt", "--keyframes", "kf.csv"],                               # unreadable par
+        ["--par", "par.txt", "--keyframes", "kf_nocol.csv"],                               # unreadable CSV
+        ["--par", "par.txt", "--keyframes"],                                               # flag without value -> usage
+        ["--keyframes", "kf.csv", "--i", "0"],                                             # usage
+    ]
+    out2 = {"files": files2, "cases": []}
+    with tempfile.TemporaryDirectory() as d2:
+        for n, txt in files2.items():
+            open(os.path.join(d2, n), "w").write(txt)
+        for args in cases2:
+            r = subprocess.run([REF2] + args, cwd=d2, capture_output=True, text=True)
+            out2["cases"].append({"args": args, "rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr})
+            print("two_frames", args, "->", r.returncode, r.stdout.count("\n"), "lines")
+    json.dump(out2, open(os.path.join(HERE, "ate_two_frames.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -13,10 +13,13 @@ import helpers as H
 TOOL = os.path.join(H.ROOT, H.PKG_NAME, "_build", "ate_keyframes")
 REF = os.path.join(H.ROOT, "oracle", "_ref", "ate_keyframes_ref")
 G = json.load(open(os.path.join(H.GOLDEN, "ate_keyframes.json")))
+TOOL2 = os.path.join(H.ROOT, H.PKG_NAME, "_build", "ate_two_frames")
+REF2 = os.path.join(H.ROOT, "oracle", "_ref", "ate_two_frames_ref")
+G2 = json.load(open(os.path.join(H.GOLDEN, "ate_two_frames.json")))
 
 
-def _write_inputs(d):
-    for name, text in G["files"].items():
+def _write_inputs(d, g=G):
+    for name, text in g["files"].items():
         (d / name).write_text(text)
 
 
@@ -39,4 +42,27 @@ def test_ate_golden_is_what_the_reference_tool_prints(tmp_path):
     _write_inputs(tmp_path)
     for case in G["cases"]:
         r = subprocess.run([REF] + case["args"], cwd=tmp_path, capture_output=True, text=True)
+        assert (r.returncode, r.stdout, r.stderr) == (case["rc"], case["stdout"], case["stderr"]), case["args"]
+
+
+@pytest.mark.parametrize("k", range(len(G2["cases"])))
+def test_ate_two_frames_matches_reference_output(k, tmp_path):
+    """BASELINE config 0's check: closed-form two-keyframe alignment (cpp/tools/ate_two_frames.cpp), incl. the parallel,
+    anti-parallel and zero-baseline branches and every error exit."""
+    assert os.path.exists(TOOL2), "run __graft_entry__.build() first"
+    case = G2["cases"][k]
+    _write_inputs(tmp_path, G2)
+    r = subprocess.run([TOOL2] + case["args"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == case["rc"], (case["args"], r.stderr)
+    assert r.stdout == case["stdout"], case["args"]
+    assert r.stderr == case["stderr"], case["args"]
+
+
+@pytest.mark.ref
+def test_ate_two_frames_golden_is_what_the_reference_tool_prints(tmp_path):
+    if not os.path.exists(REF2):
+        pytest.skip("oracle/_ref/ate_two_frames_ref not built")
+    _write_inputs(tmp_path, G2)
+    for case in G2["cases"]:
+        r = subprocess.run([REF2] + case["args"], cwd=tmp_path, capture_output=True, text=True)
         assert (r.returncode, r.stdout, r.stderr) == (case["rc"], case["stdout"], case["stderr"]), case["args"]
