@@ -11,6 +11,7 @@ import helpers as H
 synth = importlib.import_module(H.PKG_NAME + ".synth")
 REF = os.path.join(ROOT, "oracle", "_ref", "ate_keyframes_ref")
 REF2 = os.path.join(ROOT, "oracle", "_ref", "ate_two_frames_ref")
+REF3 = os.path.join(ROOT, "oracle", "_ref", "gt_keyframe_edge_ref")
 
 
 def par_text(seq):
@@ -114,6 +115,58 @@ def main():
             out2["cases"].append({"args": args, "rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr})
             print("two_frames", args, "->", r.returncode, r.stdout.count("\n"), "lines")
     json.dump(out2, open(os.path.join(HERE, "ate_two_frames.json"), "w"), indent=1)
+
+    # ---- gt_keyframe_edge: ground-truth relative pose and the error of an estimated edge
+    def rodrigues_of(i, j, noise):
+        Rij = seq["R"][j] @ seq["R"][i].T
+        th = np.arccos(np.clip((np.trace(Rij) - 1) / 2, -1, 1))
+        w = th / (2 * np.sin(th)) * np.array([Rij[2, 1] - Rij[1, 2], Rij[0, 2] - Rij[2, 0], Rij[1, 0] - Rij[0, 1]])
+        tij = seq["t"][j] - Rij @ seq["t"][i]
+        return w + noise * rng.normal(size=3), tij / np.linalg.norm(tij) * 2.5 + noise * rng.normal(size=3)
+    erows = ["i,j,kind,rvec_x,rvec_y,rvec_z,t_x,t_y,t_z"]
+    for (i, j, kind) in ((0, 1, "seq"), (1, 2, "seq"), (3, 9, "loop"), (5, 4, "seq")):
+        w, tt = rodrigues_of(i, j, 0.01)
+        erows.append(f"{i},{j},{kind}," + ",".join(f"{v:.6g}" for v in list(w) + list(tt)))
+    erows += ["7,8,seq,0,0,0,0,0,0", "bad,row", ' 2 , 6 , "quoted" , 0.1,0.2,0.3, -1,0,0 ']
+    pipeline_edges = "i,j,rvec_x,rvec_y,rvec_z,t_x,t_y,t_z,inliers,is_loop\n0,1,0.01,0.02,0.03,0.1,0.2,0.3,500,0\n"
+    shuffled = ["kf_id,frame_idx,image,x,y,z,lat,lon"] + [f"{k},{k},{seq['names'][k]},0,0,0,0,0" for k in (2, 0, 3, 1, 9)]
+    files3 = {
+        "par.txt": files["par.txt"],
+        "kf.csv": files["kf.csv"],
+        "kf_shuffled.csv": "\n".join(shuffled) + "\n",         # ids not 0..n-1 in order: remapped, id 9 dropped, id 4 a hole
+        "kf_unknown.csv": files["kf_unknown.csv"],
+        "kf_noid.csv": files["kf.csv"].replace("kf_id", "id", 1),
+        "edges.csv": "\n".join(erows) + "\n",
+        "edges_pipeline.csv": pipeline_edges,                  # the pipeline's own schema has no `kind` column
+    }
+    cases3 = [
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "0", "--j", "1"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "3", "--j", "9", "--emit-csv"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "0", "--j", "1", "--edges", "edges.csv"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "3", "--j", "9", "--edges", "edges.csv"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "5", "--j", "4", "--edges", "edges.csv"],
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "7", "--j", "8", "--edges", "edges.csv"],     # zero rotation / direction
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "2", "--j", "6", "--edges", "edges.csv"],     # padded, quoted row
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "4", "--j", "4"],                              # identity edge
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "1", "--j", "0", "--edges", "edges.csv"],     # edge missing
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "0", "--j", "1", "--edges", "edges_pipeline.csv"],  # schema mismatch
+        ["--par", "par.txt", "--keyframes", "kf_shuffled.csv", "--i", "0", "--j", "3"],
+        ["--par", "par.txt", "--keyframes", "kf_shuffled.csv", "--i", "0", "--j", "4"],                     # hole: empty image name
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "0", "--j", "99"],                             # out of range
+        ["--par", "par.txt", "--keyframes", "kf_unknown.csv", "--i", "0", "--j", "1"],                      # not in par
+        ["--par", "par.txt", "--keyframes", "kf_noid.csv", "--i", "0", "--j", "1"],                         # unreadable CSV
+        ["--par", "par.txt", "--keyframes", "kf.csv", "--i", "0", "--j", "x"],                              # usage
+        ["--par", "missing.txt", "--keyframes", "kf.csv", "--i", "0", "--j", "1"],                          # unreadable par
+    ]
+    out3 = {"files": files3, "cases": []}
+    with tempfile.TemporaryDirectory() as d3:
+        for n, txt in files3.items():
+            open(os.path.join(d3, n), "w").write(txt)
+        for args in cases3:
+            r = subprocess.run([REF3] + args, cwd=d3, capture_output=True, text=True)
+            out3["cases"].append({"args": args, "rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr})
+            print("edge", args[4:], "->", r.returncode, r.stdout.count("\n"), "lines")
+    json.dump(out3, open(os.path.join(HERE, "gt_keyframe_edge.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

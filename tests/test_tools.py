@@ -16,6 +16,9 @@ G = json.load(open(os.path.join(H.GOLDEN, "ate_keyframes.json")))
 TOOL2 = os.path.join(H.ROOT, H.PKG_NAME, "_build", "ate_two_frames")
 REF2 = os.path.join(H.ROOT, "oracle", "_ref", "ate_two_frames_ref")
 G2 = json.load(open(os.path.join(H.GOLDEN, "ate_two_frames.json")))
+TOOL3 = os.path.join(H.ROOT, H.PKG_NAME, "_build", "gt_keyframe_edge")
+REF3 = os.path.join(H.ROOT, "oracle", "_ref", "gt_keyframe_edge_ref")
+G3 = json.load(open(os.path.join(H.GOLDEN, "gt_keyframe_edge.json")))
 
 
 def _write_inputs(d, g=G):
@@ -65,4 +68,27 @@ def test_ate_two_frames_golden_is_what_the_reference_tool_prints(tmp_path):
     _write_inputs(tmp_path, G2)
     for case in G2["cases"]:
         r = subprocess.run([REF2] + case["args"], cwd=tmp_path, capture_output=True, text=True)
+        assert (r.returncode, r.stdout, r.stderr) == (case["rc"], case["stdout"], case["stderr"]), case["args"]
+
+
+@pytest.mark.parametrize("k", range(len(G3["cases"])))
+def test_gt_keyframe_edge_matches_reference_output(k, tmp_path):
+    """Ground-truth relative pose of two keyframes and the error of an estimated edge (cpp/tools/gt_keyframe_edge.cpp),
+    quirks included: the pipeline's own posegraph_edges.csv has no `kind` column and is refused by both tools."""
+    assert os.path.exists(TOOL3), "run __graft_entry__.build() first"
+    case = G3["cases"][k]
+    _write_inputs(tmp_path, G3)
+    r = subprocess.run([TOOL3] + case["args"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == case["rc"], (case["args"], r.stderr)
+    assert r.stdout == case["stdout"], case["args"]
+    assert r.stderr == case["stderr"], case["args"]
+
+
+@pytest.mark.ref
+def test_gt_keyframe_edge_golden_is_what_the_reference_tool_prints(tmp_path):
+    if not os.path.exists(REF3):
+        pytest.skip("oracle/_ref/gt_keyframe_edge_ref not built")
+    _write_inputs(tmp_path, G3)
+    for case in G3["cases"]:
+        r = subprocess.run([REF3] + case["args"], cwd=tmp_path, capture_output=True, text=True)
         assert (r.returncode, r.stdout, r.stderr) == (case["rc"], case["stdout"], case["stderr"]), case["args"]
