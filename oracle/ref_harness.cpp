@@ -376,4 +376,22 @@ void ref_global_desc_32(const std::uint8_t* pix, int w, int h, float* out1024) {
   for (int i = 0; i < 1024; i++) out1024[i] = v[(size_t)i];
 }
 
+// T:1384-1461 (sparse mesh of the points seen by one keyframe).  Points are inserted with MapState::add in array order.
+// Returns the number of vertices; *n_faces the number of faces.
+int ref_sparse_mesh(const double* K9, const double* pose12, const double* X, int n_pts, int w, int h, int max_points,
+                    int grid_px, double max_edge_px, double* verts_out, int verts_cap, int* faces_out, int faces_cap, int* n_faces) {
+  Keyframe kf;
+  kf.pose.R = wrap_m33(pose12);
+  kf.pose.t = Vec3{pose12[9], pose12[10], pose12[11]};
+  MapState map;
+  for (int p = 0; p < n_pts; p++) map.add(p, Vec3{X[3 * p], X[3 * p + 1], X[3 * p + 2]});
+  std::vector<Vec3> v;
+  std::vector<std::array<int, 3>> f;
+  build_mesh_from_sparse_points(wrap_m33(K9), kf, map.pts, w, h, max_points, grid_px, max_edge_px, v, f);
+  for (int i = 0; i < (int)v.size() && i < verts_cap; i++) { verts_out[3 * i] = v[i].x; verts_out[3 * i + 1] = v[i].y; verts_out[3 * i + 2] = v[i].z; }
+  for (int i = 0; i < (int)f.size() && i < faces_cap; i++) { faces_out[3 * i] = f[i][0]; faces_out[3 * i + 1] = f[i][1]; faces_out[3 * i + 2] = f[i][2]; }
+  *n_faces = (int)f.size();
+  return (int)v.size();
+}
+
 }  // extern "C"

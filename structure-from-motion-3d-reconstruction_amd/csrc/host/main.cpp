@@ -2,8 +2,7 @@
 // on one MI355X through libsfmx.  Same positional arguments, flags, config.json lookup, stdout lines,
 // CSV / PLY outputs and exit codes (2 usage, 0 ok/help, 1 "ERROR: ...").
 //
-// Out of scope: the Bowyer-Watson mesh export.  --export-geometry mesh|both is parsed
-// like the reference; the mesh file itself is not produced and a WARN line says so.
+// --export-geometry mesh|both writes templeRing_mesh_sparse_kf<k>.ply through mesh.cpp (T:1884-1906).
 #include <filesystem>
 #include <iostream>
 #include <optional>
@@ -96,6 +95,7 @@ int main(int argc, char** argv) {
     bool export_geom_from_cli = false;
     int mesh_kf = 0, mesh_max_points = 2500, mesh_grid_px = 4;
     double mesh_max_edge_px = 80.0;
+    bool mesh_kf_cli = false, mesh_max_points_cli = false, mesh_grid_px_cli = false, mesh_max_edge_px_cli = false;
     PipelineConfig pc;
     while (argi < argc) {
       const std::string flag = argv[argi++];
@@ -111,14 +111,13 @@ int main(int argc, char** argv) {
         export_geom = *eg;
         export_geom_from_cli = true;
       }
-      else if (flag == "--mesh-kf") mesh_kf = std::stoi(need(flag));
-      else if (flag == "--mesh-max-points") mesh_max_points = std::stoi(need(flag));
-      else if (flag == "--mesh-grid-px") mesh_grid_px = std::stoi(need(flag));
-      else if (flag == "--mesh-max-edge-px") mesh_max_edge_px = std::stod(need(flag));
+      else if (flag == "--mesh-kf") { mesh_kf = std::stoi(need(flag)); mesh_kf_cli = true; }
+      else if (flag == "--mesh-max-points") { mesh_max_points = std::stoi(need(flag)); mesh_max_points_cli = true; }
+      else if (flag == "--mesh-grid-px") { mesh_grid_px = std::stoi(need(flag)); mesh_grid_px_cli = true; }
+      else if (flag == "--mesh-max-edge-px") { mesh_max_edge_px = std::stod(need(flag)); mesh_max_edge_px_cli = true; }
       else if (flag == "-h" || flag == "--help") { std::cerr << "Run without args to see usage.\n"; return 0; }
       else throw std::runtime_error("Unknown option: " + flag);
     }
-    (void)mesh_kf; (void)mesh_max_points; (void)mesh_grid_px; (void)mesh_max_edge_px;
     if (!have_config) {
       const fs::path local = fs::path("config.json");
       if (fs::exists(local)) { config_path = local; have_config = true; }
@@ -137,6 +136,10 @@ int main(int argc, char** argv) {
       if (!export_geom_from_cli)
         if (auto s = jstring(jpick(*cfg, "outputs", "export_geometry")))
           if (const auto eg = parse_export_geometry(*s)) export_geom = *eg;
+      if (!mesh_kf_cli) if (auto v = jint(jpick(*cfg, "mesh_sparse", "kf"))) mesh_kf = *v;  // T:1642-1653
+      if (!mesh_max_points_cli) if (auto v = jint(jpick(*cfg, "mesh_sparse", "max_points"))) mesh_max_points = *v;
+      if (!mesh_grid_px_cli) if (auto v = jint(jpick(*cfg, "mesh_sparse", "grid_px"))) mesh_grid_px = *v;
+      if (!mesh_max_edge_px_cli) if (auto v = jdouble(jpick(*cfg, "mesh_sparse", "max_edge_px"))) mesh_max_edge_px = *v;
       if (auto v = jint(jpick(*cfg, "klt", "max_tracks"))) pc.klt.max_tracks = *v;
       if (auto v = jint(jpick(*cfg, "klt", "min_tracks"))) pc.klt.min_tracks = *v;
       if (auto v = jdouble(jpick(*cfg, "klt", "quality"))) pc.klt.quality = *v;
@@ -191,8 +194,20 @@ int main(int argc, char** argv) {
     run_pipeline(ctx, src, meta, K, pc, res, echo_line);
     const size_t printed = res.log.size();
     write_outputs(out.string(), pc, meta, res);
-    if (export_geom == ExportGeometry::MESH || export_geom == ExportGeometry::BOTH)
-      std::cerr << "WARN: mesh export is outside the sfmx hot-path scope; templeRing_mesh_sparse_kf<k>.ply not written.\n";
+    if (export_geom == ExportGeometry::MESH || export_geom == ExportGeometry::BOTH) {  // T:1884-1906
+      if (res.kfs.empty()) {
+        std::cerr << "WARN: mesh export skipped (no keyframes).\n";
+      } else {
+        const int kidx = std::max(0, std::min(mesh_kf, (int)res.kfs.size() - 1));
+        const Keyframe& mkf = res.kfs[(size_t)kidx];
+        const Gray im = read_pgm((src.dir / fs::path(mkf.img_name).replace_extension(".pgm")).string());  // its size bounds the projection
+        std::vector<V3> verts;
+        std::vector<std::array<int, 3>> faces;
+        build_sparse_mesh(K, mkf.pose, res.map, im.w, im.h, mesh_max_points, mesh_grid_px, mesh_max_edge_px, verts, faces);
+        if (verts.empty() || faces.empty()) std::cerr << "WARN: mesh export skipped (insufficient projected points or no valid triangles).\n";
+        else write_mesh_ply((out / (std::string("templeRing_mesh_sparse_kf") + std::to_string(kidx) + ".ply")).string(), verts, faces);
+      }
+    }
     std::cout << res.log.substr(printed);
     if (std::getenv("SFMX_TIMING")) {
       const StageClock& c = res.clock;

@@ -3,6 +3,7 @@
 // the sfmx C ABI, plus the per-frame loop of main() (T:1686-1911) and its CSV/PLY writers.
 // Nothing here falls back to CPU arithmetic for the hot kernels: a failing C-ABI call is an error.
 #pragma once
+#include <array>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -401,6 +402,11 @@ class AsyncLane {
 };
 
 bool posegraph_optimize_centers(sfmx_ctx* ctx, std::vector<Keyframe>& kfs, const std::vector<PGEdge>& edges);
+
+// optional sparse-mesh export of the CLI (mesh.cpp; T:1226-1461): empty outputs = skipped
+void build_sparse_mesh(const Mat3& K, const Pose& kf_pose, const MapState& map, int img_w, int img_h, int max_points, int grid_px,
+                       double max_edge_px, std::vector<V3>& vertices, std::vector<std::array<int, 3>>& faces);
+void write_mesh_ply(const std::string& path, const std::vector<V3>& vertices, const std::vector<std::array<int, 3>>& faces);
 
 struct PipelineConfig {
   int frames = 12;

@@ -125,6 +125,39 @@ def test_cli_drop_in(tmp_path):
     assert q.returncode == 0 and q.stdout.count("frame ") == 3
 
 
+def test_cli_mesh_export(tmp_path):
+    """--export-geometry both on a 640x480 run: the mesh PLY is well formed, its vertices are map points (the PLY writers
+    print 6 significant digits), its faces index them, and the file does not depend on the lane schedule.  The mesh
+    builder itself is pinned to the reference function bit for bit in tests/test_host_math.py."""
+    seq = synth.make_sequence(5, 640, 480, 0.3, n_blobs=20000, seed=7)
+    root = str(tmp_path / "data")
+    synth.write_dataset(root, seq)
+    outs = []
+    for k, extra in enumerate(({}, {"SFMX_NO_ASYNC": "1", "SFMX_NO_PREFETCH": "1"})):
+        out = os.path.join(root, f"out{k}")
+        p = subprocess.run([pipe.CLI_PATH, root, out, "5", "--export-geometry", "both", "--mesh-kf", "2", "--mesh-max-points", "400"],
+                           capture_output=True, text=True, cwd=str(tmp_path), env={**os.environ, **extra})
+        assert p.returncode == 0 and "WARN" not in p.stderr, p.stderr
+        outs.append(out)
+    mesh = open(os.path.join(outs[0], "templeRing_mesh_sparse_kf2.ply")).read()
+    assert mesh == open(os.path.join(outs[1], "templeRing_mesh_sparse_kf2.ply")).read()
+    lines = mesh.splitlines()
+    nv = int([l for l in lines if l.startswith("element vertex")][0].split()[-1])
+    nf = int([l for l in lines if l.startswith("element face")][0].split()[-1])
+    body = lines[lines.index("end_header") + 1:]
+    assert 50 <= nv <= 400 and nf > nv and len(body) == nv + nf
+    cloud = open(os.path.join(outs[0], "templeRing_sparse_points.ply")).read().splitlines()
+    cloud_pts = set(cloud[cloud.index("end_header") + 1:])
+    assert all(v in cloud_pts for v in body[:nv])
+    faces = np.array([[int(x) for x in l.split()] for l in body[nv:]])
+    assert np.all(faces[:, 0] == 3) and faces[:, 1:].min() >= 0 and faces[:, 1:].max() < nv
+    # too few points in view: the reference's warning, no file, exit 0
+    out = os.path.join(root, "out_few")
+    p = subprocess.run([pipe.CLI_PATH, root, out, "1", "--export-geometry", "mesh"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0 and p.stderr.strip().endswith("WARN: mesh export skipped (insufficient projected points or no valid triangles).")
+    assert not os.path.exists(os.path.join(out, "templeRing_mesh_sparse_kf0.ply")) and not os.path.exists(os.path.join(out, "templeRing_sparse_points.ply"))
+
+
 def test_long_sequence_lanes_equal_serial(ctx, tmp_path, monkeypatch):
     """120 frames (every one a keyframe, loop closures being verified all along): the five-lane schedule, run twice, and
     the fully serial one must write the same bytes -- the short CLI sequences above hardly fill the tracker lane's ring."""

@@ -121,3 +121,23 @@ def test_arena_map_iterates_like_default_unordered_map():
                b.ctypes.data_as(ctypes.c_void_p))
         assert k >= 0
         assert np.array_equal(a[:k], b[:k]), (n, span, erase)
+
+
+def test_sparse_mesh_matches_reference():
+    """--export-geometry mesh (mesh.cpp): projection, shuffled grid thinning, Bowyer-Watson, long-edge filter.  Vertices
+    (bitwise) and faces must be what the reference's build_mesh_from_sparse_points returned on the committed inputs
+    (tests/golden/make_mesh_golden.py; incl. a regular lattice = cocircular points, < 50 points, all behind the camera)."""
+    import os
+    g = np.load(os.path.join(H.GOLDEN, "mesh.npz"))
+    for name in [str(n) for n in g["names"]]:
+        X = np.ascontiguousarray(g[name + "_X"])
+        w, h, mp, gp, me = g[name + "_cfg"]
+        cap = max(len(X), 1)
+        v = np.zeros((cap, 3))
+        f = np.zeros((cap * 4, 3), np.int32)
+        nf = np.zeros(1, np.int32)
+        nv = L.call("sfmx_host_sparse_mesh", int, H.f64(g[name + "_K"]), H.f64(g[name + "_pose"]), H.f64(X), len(X), int(w), int(h), int(mp),
+                    int(gp), float(me), v, cap, f, cap * 4, nf)
+        assert nv == len(g[name + "_v"]) and int(nf[0]) == len(g[name + "_f"]), name
+        H.assert_bits_equal(v[:nv], g[name + "_v"], f"mesh vertices ({name})")
+        assert np.array_equal(f[:int(nf[0])], g[name + "_f"]), name
