@@ -27,6 +27,11 @@ import sys
 import tempfile
 import time
 
+# One pipeline keeps five contexts busy.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
+# 4) in creation order; with 8 the BA lane, the tracker lane and the prefetch lane each get a queue of their own
+# (measured: +15-20 % keyframes/s).  Must be in the environment before the HIP runtime initialises, i.e. before torch.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -78,6 +83,11 @@ def main():
     ap.add_argument("--max-tracks", type=int, default=2200)
     ap.add_argument("--cpu-sample-frames", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequences-per-gpu", type=int, default=1,
+                    help="independent sequences in flight on each GPU (a batch of S sequences per step); the headline uses 1")
+    ap.add_argument("--batched-probe", type=int, default=3,
+                    help="after the headline measurement (1 sequence per GPU) also time this many sequences in flight and "
+                         "report it as `batched` (single-GPU runs only; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -91,49 +101,90 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     capi = importlib.import_module(PKG + ".capi")
     pipe = importlib.import_module(PKG + ".pipeline")
     synth = importlib.import_module(PKG + ".synth")
 
-    # --- synthetic TempleRing-47 stand-in (one independent sequence per rank)
-    seq = synth.make_sequence(args.frames, 640, 480, args.deg_per_frame, n_blobs=20000, seed=7 + rank)
+    # --- synthetic TempleRing-47 stand-in: S independent sequences per rank, each with its own context and host thread
+    # (one sequence alone cannot fill the device: its kernels are short dependent chains)
+    import threading
+    S = max(1, args.sequences_per_gpu)
     cfg = dict(pipe.DEFAULTS, frames=args.frames, max_tracks=args.max_tracks, min_tracks=min(900, args.max_tracks * 9 // 22),
                export_pointcloud=0)
-    ctx = capi.Context(local_rank)
-    frames_dev = torch.from_numpy(np.ascontiguousarray(seq["images"])).to(f"cuda:{local_rank}")  # resident in HBM
-    torch.cuda.synchronize()
+    seqs, ctxs, devs = [], [], []
+
+    def ensure_sequences(n):  # contexts are created only when used: idle streams still take part in the HW-queue mapping
+        while len(seqs) < n:
+            q = len(seqs)
+            seqs.append(synth.make_sequence(args.frames, 640, 480, args.deg_per_frame, n_blobs=20000, seed=7 + rank + 101 * q))
+            ctxs.append(capi.Context(local_rank))
+            devs.append(torch.from_numpy(np.ascontiguousarray(seqs[q]["images"])).to(f"cuda:{local_rank}"))  # resident in HBM
+        torch.cuda.synchronize()
+
+    ensure_sequences(S)
+    seq, ctx, frames_dev = seqs[0], ctxs[0], devs[0]
     shape = tuple(frames_dev.shape)
 
-    def one_pass(timing=False):
-        return pipe.run(ctx, None, seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, None, images_dev=frames_dev.data_ptr(),
-                        shape=shape, timing=timing)
-
-    for _ in range(args.warmup):
-        one_pass()
+    def one_pass(timing=False, q=0):
+        return pipe.run(ctxs[q], None, seqs[q]["names"], seqs[q]["K"], seqs[q]["lat"], seqs[q]["lon"], cfg, None,
+                        images_dev=devs[q].data_ptr(), shape=shape, timing=timing)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    kf_total = 0
-    last = None
-    identical = True  # five host lanes reorder WHEN work happens, never WHAT comes out: every pass must agree bit for bit
-    for _ in range(args.steps):
-        cur_pass = one_pass()
-        if last is not None:
-            identical = identical and cur_pass["log"] == last["log"] and np.array_equal(
-                cur_pass["centres"].view(np.uint64), last["centres"].view(np.uint64))
-        last = cur_pass
-        kf_total += last["stats"]["n_keyframes"]
-    ctx.sync()
-    barrier()
-    dt = time.perf_counter() - t0
+    # The pipeline's contexts (and with them their streams) are created by the first pass.  RCCL comes up only after that,
+    # so that a rank's streams get the same hardware queues as in a single-process run (csrc/hip/ctx.hip).
+    one_pass()
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def measure(n_seq, n_warm, n_steps):
+        """n_seq sequences in flight (one host thread + context each): wall time of n_steps passes of every sequence.
+        Every pass of a sequence must agree bit for bit: the host lanes reorder WHEN work happens, never WHAT comes out."""
+        ensure_sequences(n_seq)
+        result = [dict(kf=0, identical=True, last=None, error=None) for _ in range(n_seq)]
+
+        def worker(q, n_pass, count):
+            try:
+                for _ in range(n_pass):
+                    cur = one_pass(q=q)
+                    r = result[q]
+                    if count:
+                        if r["last"] is not None:
+                            r["identical"] = r["identical"] and cur["log"] == r["last"]["log"] and np.array_equal(
+                                cur["centres"].view(np.uint64), r["last"]["centres"].view(np.uint64))
+                        r["kf"] += cur["stats"]["n_keyframes"]
+                    r["last"] = cur
+            except Exception as e:  # surfaced after the join
+                result[q]["error"] = e
+
+        def run_all(n_pass, count):
+            if n_seq == 1:
+                worker(0, n_pass, count)
+            else:
+                th = [threading.Thread(target=worker, args=(q, n_pass, count)) for q in range(n_seq)]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+            for r in result:
+                if r["error"] is not None:
+                    raise r["error"]
+
+        run_all(n_warm, False)
+        barrier()
+        t_start = time.perf_counter()
+        run_all(n_steps, True)
+        for c in ctxs[:n_seq]:
+            c.sync()
+        barrier()
+        wall = time.perf_counter() - t_start
+        return wall, sum(r["kf"] for r in result), all(r["identical"] for r in result), result[0]["last"]
+
+    dt, kf_total, identical, last = measure(S, args.warmup, args.steps)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -144,6 +195,12 @@ def main():
 
     # --- one extra, untimed pass with per-kernel HIP-event timing for the roofline object
     prof = one_pass(timing=True)["stats"]
+    batched = None
+    if world == 1 and S == 1 and args.batched_probe > 1:  # how much more the device takes with several sequences in flight
+        b_steps = max(2, min(args.steps, 8))
+        b_dt, b_kf, b_same, _ = measure(args.batched_probe, 1, b_steps)
+        batched = {"sequences_per_gpu": args.batched_probe, "value": round(b_kf / b_dt, 3), "unit": "keyframes/s", "steps": b_steps,
+                   "ms_per_step": round(b_dt / b_steps * 1e3, 3), "passes_bit_identical": bool(b_same)}
     if rank == 0:
         st = last["stats"]
         per_stage = {"klt": prof["us_klt_kernel"], "ransac": prof["us_ransac_kernel"], "ba": prof["us_ba_kernel"], "shi": prof["us_shi_kernel"]}
@@ -214,9 +271,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic TempleRing-47 stand-in: {args.frames} frames 640x480 u8, ring camera {args.deg_per_frame} deg/frame, "
                                    f"reference default config (max_tracks={args.max_tracks}, RANSAC 2500 iters, BA window 6 / 600 pts / 5 iters); "
-                                   "one independent sequence per GPU", "frames_per_step": args.frames, "parallelism": f"sequences x{world}"},
-            "frames_per_s": round(args.frames * args.steps * world / dt, 2),
-            "keyframes_per_step": st["n_keyframes"], "map_points": st["n_points"], "passes_bit_identical": bool(identical),
+                                   f"{S} independent sequence(s) in flight per GPU", "frames_per_step": args.frames * S, "sequences_per_gpu": S,
+                       "parallelism": f"sequences x{world * S}"},
+            "frames_per_s": round(args.frames * args.steps * world * S / dt, 2),
+            "keyframes_per_step": int(round(kf_total / max(1, args.steps) / world)), "map_points": st["n_points"], "passes_bit_identical": bool(identical),
             "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_wall", "sec_total", "sec_setup", "sec_klt", "sec_shi", "sec_shi_wait", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_pf_busy", "sec_pf_gpu", "sec_pf_replay", "sec_lane_b_busy", "sec_lane_c_busy", "sec_join_wait", "sec_ba_gather", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_feed_wait")},
             "counters_per_step": {k: int(st[k]) for k in ("klt_calls", "tracks_in", "lk_steps", "ransac_calls", "ransac_points", "ransac_verified", "ba_calls", "ba_iters", "shi_calls", "shi_memo_hits", "shi_prefetched", "shi_fallbacks")},
             "roofline": roofline,
@@ -224,6 +282,7 @@ def main():
         # ATE-RMSE of the keyframe centres against the synthetic ground truth, stated by the build's own evaluator
         # (structure-from-motion-3d-reconstruction_amd/_build/ate_keyframes; its digits are pinned to the reference tool's
         # in tests/test_tools.py) on the CSV of one extra, untimed pass
+        out["batched"] = batched
         out["ate_rmse_sim3_vs_gt"] = None
         try:
             import subprocess, tempfile
@@ -250,7 +309,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,10 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_uint8, 
 
 import numpy as np
 
+# the pipeline keeps five streams busy; HIP's default of 4 hardware queues makes lanes share one.
+# Only effective if the HIP runtime has not initialised yet (bench.py sets it before importing torch).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libsfmx.so")
 

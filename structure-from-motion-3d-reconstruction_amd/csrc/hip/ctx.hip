@@ -28,8 +28,12 @@ int sfmx_ctx_create_prio(int device_id, int priority, sfmx_ctx** out) {
   int lo = 0, hi = 0;  // HIP: numerically lower = higher priority; range [hi, lo]
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   const int prio = priority < 0 ? hi : (priority > 0 ? lo : (lo + hi) / 2);
-  if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess ||
-      hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio) != hipSuccess ||
+  // HIP hands streams to its hardware queues (GPU_MAX_HW_QUEUES, set to 8 by the CLI and bench.py) in creation order.
+  // With the copy stream created FIRST, the compute streams of the five pipeline contexts land on queues that do not
+  // share with each other (only lane C, which the geometry lane waits for anyway, doubles up with it); the opposite order
+  // puts the BA lane next to the prefetch lane and costs 15-20 % keyframes/s (measured on MI355X).
+  if (hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio) != hipSuccess ||
+      hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return SFMX_ERR_HIP;

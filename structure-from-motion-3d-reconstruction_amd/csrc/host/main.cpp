@@ -3,6 +3,7 @@
 // CSV / PLY outputs and exit codes (2 usage, 0 ok/help, 1 "ERROR: ...").
 //
 // --export-geometry mesh|both writes templeRing_mesh_sparse_kf<k>.ply through mesh.cpp (T:1884-1906).
+#include <cstdlib>
 #include <filesystem>
 #include <iostream>
 #include <optional>
@@ -58,6 +59,8 @@ void echo_line(const std::string& s) { std::cout << s; }
 }  // namespace
 
 int main(int argc, char** argv) {
+  // the pipeline keeps five streams busy; HIP's default of 4 hardware queues makes lanes share one
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   try {
     if (argc < 3) {
       std::cerr << "Usage: " << argv[0] << " <templering_root> <out_dir> [frames] [options]\n"

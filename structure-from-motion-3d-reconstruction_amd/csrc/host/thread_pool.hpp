@@ -1,4 +1,4 @@
-// thread_pool.hpp — a tiny persistent pool for the host-side libm-bound small solves (DLT
+// thread_pool.hpp — tiny persistent worker teams for the host-side libm-bound small solves (DLT
 // triangulations, cheirality votes).  Work items are independent and their results are written to
 // pre-sized slots, so the outcome is identical to the sequential loop for any thread count.
 #pragma once
@@ -13,22 +13,27 @@
 
 namespace sfmx_host {
 
-class ThreadPool {
+// One team of worker threads; parallel_for is used by one caller at a time.
+class WorkerTeam {
  public:
-  static ThreadPool& instance() {
-    static ThreadPool p;
-    return p;
+  WorkerTeam() {
+    int want = 0;
+    if (const char* e = std::getenv("SFMX_HOST_THREADS")) want = std::atoi(e);
+    if (want <= 0) want = std::min(8, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+    for (int i = 1; i < want; i++) workers_.emplace_back([this] { worker(); });
   }
-  int size() const { return (int)workers_.size() + 1; }
-  // calls fn(i) for i in [0,n); the calling thread participates.
-  void parallel_for(int n, const std::function<void(int)>& fn, int grain = 16) {
-    if (n <= 0) return;
-    // one parallel region at a time: a second caller (another pipeline lane) simply runs its items serially
-    std::unique_lock<std::mutex> region(region_mu_, std::try_to_lock);
-    if (workers_.empty() || n <= grain || !region.owns_lock()) {
-      for (int i = 0; i < n; i++) fn(i);
-      return;
+  ~WorkerTeam() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+      ++epoch_;
     }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  bool solo() const { return workers_.empty(); }
+  // calls fn(i) for i in [0,n); the calling thread participates.
+  void parallel_for(int n, const std::function<void(int)>& fn, int grain) {
     {
       std::lock_guard<std::mutex> lk(m_);
       fn_ = &fn;
@@ -46,21 +51,6 @@ class ThreadPool {
   }
 
  private:
-  ThreadPool() {
-    int want = 0;
-    if (const char* e = std::getenv("SFMX_HOST_THREADS")) want = std::atoi(e);
-    if (want <= 0) want = std::min(8, std::max(1, (int)std::thread::hardware_concurrency() / 2));
-    for (int i = 1; i < want; i++) workers_.emplace_back([this] { worker(); });
-  }
-  ~ThreadPool() {
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
-      ++epoch_;
-    }
-    cv_.notify_all();
-    for (auto& t : workers_) t.join();
-  }
   void run_chunks() {
     for (;;) {
       const int b = next_.fetch_add(grain_);
@@ -86,13 +76,51 @@ class ThreadPool {
     }
   }
   std::vector<std::thread> workers_;
-  std::mutex m_, region_mu_;
+  std::mutex m_;
   std::condition_variable cv_, done_cv_;
   const std::function<void(int)>* fn_ = nullptr;
   int n_ = 0, grain_ = 16, pending_ = 0;
   std::atomic<int> next_{0};
   unsigned long epoch_ = 0;
   bool stop_ = false;
+};
+
+// Process-wide front end: every parallel region borrows a team for its duration, so that the lanes of one pipeline and
+// several pipelines in one process (one sequence per host thread) never wait for each other; teams are created on
+// demand and kept for reuse.
+class ThreadPool {
+ public:
+  static ThreadPool& instance() {
+    static ThreadPool* p = new ThreadPool;  // kept until process exit: no joins from static destructors
+    return *p;
+  }
+  void parallel_for(int n, const std::function<void(int)>& fn, int grain = 16) {
+    if (n <= 0) return;
+    if (n <= grain) {
+      for (int i = 0; i < n; i++) fn(i);
+      return;
+    }
+    WorkerTeam* team = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!idle_.empty()) {
+        team = idle_.back();
+        idle_.pop_back();
+      }
+    }
+    if (!team) team = new WorkerTeam;
+    if (team->solo()) {
+      for (int i = 0; i < n; i++) fn(i);
+    } else {
+      team->parallel_for(n, fn, grain);
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    idle_.push_back(team);
+  }
+
+ private:
+  std::mutex mu_;
+  std::vector<WorkerTeam*> idle_;
 };
 
 }  // namespace sfmx_host
