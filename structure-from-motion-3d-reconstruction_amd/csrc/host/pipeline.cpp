@@ -277,12 +277,12 @@ ContextPool& ContextPool::instance() {
   static ContextPool* p = new ContextPool;  // leaked on purpose, see pipeline.hpp
   return *p;
 }
-PooledCtx* ContextPool::acquire(int device, int priority) {
+PooledCtx* ContextPool::acquire(int device, int priority, int role) {
   static const bool no_pool = std::getenv("SFMX_NO_CTX_POOL") != nullptr;
   if (!no_pool) {
     std::lock_guard<std::mutex> lk(mu_);
     for (size_t i = 0; i < free_.size(); i++)
-      if (free_[i]->device == device && free_[i]->priority == priority) {
+      if (free_[i]->device == device && free_[i]->priority == priority && free_[i]->role == role) {
         PooledCtx* pc = free_[i];
         free_.erase(free_.begin() + (long)i);
         return pc;
@@ -291,6 +291,7 @@ PooledCtx* ContextPool::acquire(int device, int priority) {
   auto pc = std::make_unique<PooledCtx>();
   pc->device = device;
   pc->priority = priority;
+  pc->role = role;
   check(nullptr, sfmx_ctx_create_prio(device, priority, &pc->ctx), "ctx_create(helper)");
   return pc.release();
 }
@@ -360,7 +361,7 @@ CornerPrefetcher::CornerPrefetcher(int device, FrameSource& src, double quality,
   try {
     for (int i = 0; i < std::max(1, workers); ++i) {
       auto w = std::make_unique<Worker>();
-      w->pc = ContextPool::instance().acquire(device, prio_env("SFMX_PRIO_PREFETCH", 0));
+      w->pc = ContextPool::instance().acquire(device, prio_env("SFMX_PRIO_PREFETCH", 0), ContextPool::PREFETCH);
       w->ctx = w->pc->ctx;
       workers_.push_back(std::move(w));
       Worker& ww = *workers_.back();
@@ -845,8 +846,8 @@ void GpuBundleAdjuster::apply(const BaJob& job, std::vector<Keyframe>& kfs) {
 }
 
 // ------------------------------------------------------------------------------------------ async lane
-AsyncLane::AsyncLane(int device, int priority) {
-  pc_ = ContextPool::instance().acquire(device, priority);
+AsyncLane::AsyncLane(int device, int priority, int role) {
+  pc_ = ContextPool::instance().acquire(device, priority, role);
   ctx_ = pc_->ctx;
   th_ = std::thread([this] { run(); });
 }
@@ -997,7 +998,7 @@ FrameFeeder::FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig&
                          bool threaded, CornerPrefetcher* prefetch, int prefetch_depth, StageClock* clk)
     : src_(src), desc_level_(desc_level), n_frames_(n_frames), prefetch_depth_(prefetch_depth), prefetch_(prefetch), ctx_(caller_ctx), clk_(clk) {
   if (threaded) {
-    pc_ = ContextPool::instance().acquire(sfmx_ctx_device(caller_ctx), prio_env("SFMX_PRIO_TRACKER", 0));
+    pc_ = ContextPool::instance().acquire(sfmx_ctx_device(caller_ctx), prio_env("SFMX_PRIO_TRACKER", 0), ContextPool::TRACKER);
     ctx_ = pc_->ctx;
     if (sfmx_get_timing(caller_ctx)) (void)sfmx_set_timing(ctx_, 1);
     clk_ = &lane_clk_;
@@ -1110,6 +1111,30 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   if (dlevel + 1 > 8 || cfg.klt.pyr_levels > 8) throw SfmxFailure(SFMX_ERR_UNSUPPORTED, "image too large for an 8-level pyramid");
   // one worker keeps frame f+1 in flight; more (SFMX_PREFETCH_WORKERS) remove the residual wait but the extra
   // contexts slow the other lanes down by more than that on one GPU (measured: 1 -> 552, 2 -> 498, 3 -> 510 kf/s)
+  // Stream creation order decides which hardware queue a lane's stream lands on (csrc/hip/ctx.hip), and the pool hands
+  // every lane the same context again on later runs.  The helper contexts are therefore created up front, in a fixed
+  // order, the first time a device is used: T(racker) B P(refetch) C -- all 24 orders were measured on MI355X with
+  // GPU_MAX_HW_QUEUES=8 (705-877 keyframes/s; the BA lane must not end up on the geometry lane's queue, which is where the
+  // fourth context goes).  SFMX_LANE_ORDER overrides it for experiments.
+  {
+    static std::mutex once_mu;
+    static std::vector<int> warmed_devices;
+    std::lock_guard<std::mutex> lk(once_mu);
+    const int dev = sfmx_ctx_device(ctx);
+    if (std::find(warmed_devices.begin(), warmed_devices.end(), dev) == warmed_devices.end() && !std::getenv("SFMX_NO_ASYNC") &&
+        !std::getenv("SFMX_NO_CTX_POOL")) {
+      warmed_devices.push_back(dev);
+      const char* order = std::getenv("SFMX_LANE_ORDER");
+      if (!order) order = "TBPC";
+      std::vector<PooledCtx*> made;
+      for (const char* c = order; *c; ++c) {
+        const int role = *c == 'P' ? ContextPool::PREFETCH : *c == 'T' ? ContextPool::TRACKER : *c == 'B' ? ContextPool::LANE_B
+                         : *c == 'C' ? ContextPool::LANE_C : 0;
+        if (role) made.push_back(ContextPool::instance().acquire(dev, 0, role));
+      }
+      for (PooledCtx* pc : made) ContextPool::instance().release(pc);
+    }
+  }
   int prefetch_workers = 1;
   if (const char* e = std::getenv("SFMX_PREFETCH_WORKERS")) prefetch_workers = std::min(4, std::max(1, std::atoi(e)));
   std::unique_ptr<CornerPrefetcher> prefetch;
@@ -1141,8 +1166,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   StageClock lane_clk, lane_c_clk;
   std::unique_ptr<AsyncLane> lane, lane_c;
   if (use_lane) {
-    lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_B", 0));
-    lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_C", 0));
+    lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_B", 0), ContextPool::LANE_B);
+    lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_C", 0), ContextPool::LANE_C);
   }
   if (sfmx_get_timing(ctx)) {  // per-kernel event timing is inherited by the helper contexts
     if (lane) (void)sfmx_set_timing(lane->ctx(), 1);

@@ -88,6 +88,7 @@ struct StageClock {
 struct PooledCtx {
   sfmx_ctx* ctx = nullptr;
   int device = 0, priority = 0;
+  int role = 0;                 // which lane it serves: the same lane gets the same context (and hardware queue) every run
   sfmx_pyramid* pyr = nullptr;  // one scratch pyramid that lives with the context
   int pw = 0, ph = 0, pl = 0;
   sfmx_pyramid* pyramid(int w, int h, int levels);  // (re)created when the geometry changes
@@ -99,7 +100,8 @@ struct PooledCtx {
 class ContextPool {
  public:
   static ContextPool& instance();
-  PooledCtx* acquire(int device, int priority);
+  enum Role { PREFETCH = 1, TRACKER = 2, LANE_B = 3, LANE_C = 4 };
+  PooledCtx* acquire(int device, int priority, int role);
   void release(PooledCtx* pc);  // synchronises the context; the caller's threads must have stopped using it
   void clear();
 
@@ -378,7 +380,7 @@ class GpuBundleAdjuster {
 // Tasks run in submission order; wait() blocks until the lane is idle and rethrows the first task exception.
 class AsyncLane {
  public:
-  AsyncLane(int device, int priority);  // priority: sfmx_ctx_create_prio
+  AsyncLane(int device, int priority, int role);  // priority: sfmx_ctx_create_prio; role: ContextPool::Role
   ~AsyncLane();
   AsyncLane(const AsyncLane&) = delete;
   AsyncLane& operator=(const AsyncLane&) = delete;
