@@ -107,10 +107,30 @@ int sfmx_klt_track(sfmx_ctx* ctx, const sfmx_pyramid* pyr_a, const sfmx_pyramid*
 /* ---- RANSAC scoring: replaces the hypothesis loop of find_E_ransac (T:664-677) --------------- */
 /* xi,xj: K^-1-normalised correspondences [n][2]; idx8: pre-drawn sample octets [H][8] (the
  * caller draws them with the libstdc++-compatible generator so the stream matches T:657-665).
- * The device builds every 8-point hypothesis (A6-A11), scores all n points per hypothesis with the
- * Sampson error (T:629-638) and counts err < thr.  counts_out [H] (optional) receives every count;
- * best_iter/best_count = argmax with the LOWEST iteration on ties (the reference's strict '>').
- * E_out [H][9] (optional) receives the device hypotheses. */
+ * Every 8-point hypothesis (T:609-627) is built and all n points are scored against it with the
+ * Sampson error (T:629-638, bit-exact arithmetic for a given E), counting err < thr.
+ *
+ * Which E a hypothesis is scored with.  The reference's eight_point_E calls the platform libm
+ * (atan2/cos/sin, linalg.hpp:156-157); the device runs the same Jacobi with algebraic rotations,
+ * whose result differs from the reference's by rounding only while the smallest eigenvector is
+ * well separated.  Where it is not -- octets with a repeated sample index (sampling is with
+ * replacement, T:665: null space of dimension >= 2), an eigenvalue / singular-value gap below
+ * 1e-5 relative, or a Jacobi pivot nearly tied with another entry -- the library derives the
+ * hypothesis on the host with libm (the reference's E bit for bit) and scores that instead
+ * (flags bit 0).
+ *
+ * counts_out [H]: #{err < thr}.  lo_out/hi_out [H] (optional): #{err < thr(1-1e-6)} and
+ * #{err < thr(1+1e-6)} -- the reference's own count lies in [lo, hi] (the band absorbs the
+ * rounding distance between a device hypothesis and the reference's); lo == hi == count for the
+ * exact hypotheses.  flags_out [H] (optional): bit 0 = exact host hypothesis.  cond_out [H]
+ * (optional): conditioning estimate of the device hypothesis.  best_iter/best_count = argmax of
+ * counts with the LOWEST iteration on ties (the reference's strict '>').  E_out [H][9]
+ * (optional): the hypotheses that were scored. */
+int sfmx_ransac_score_ex(sfmx_ctx* ctx, const double* xi, const double* xj, int n, const int32_t* idx8,
+                         int H, double thr, int32_t* counts_out, int32_t* lo_out, int32_t* hi_out,
+                         uint8_t* flags_out, double* cond_out, int32_t* best_iter,
+                         int32_t* best_count, double* E_out);
+/* same without the certification outputs */
 int sfmx_ransac_score(sfmx_ctx* ctx, const double* xi, const double* xj, int n, const int32_t* idx8,
                       int H, double thr, int32_t* counts_out, int32_t* best_iter, int32_t* best_count,
                       double* E_out);

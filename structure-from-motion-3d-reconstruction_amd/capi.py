@@ -25,7 +25,7 @@ SYMBOLS = [
     "sfmx_ctx_create", "sfmx_ctx_create_prio", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_ctx_device", "sfmx_ctx_make_current", "sfmx_stream", "sfmx_set_timing", "sfmx_get_timing",
     "sfmx_last_kernel_us", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
-    "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_sampson_mask", "sfmx_ba_create",
+    "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_ransac_score_ex", "sfmx_sampson_mask", "sfmx_ba_create",
     "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt",
 ]
@@ -242,6 +242,21 @@ class Context:
                                              c_int(H), c_double(thr), _p(counts, c_int32), byref(bi), byref(bc),
                                              _p(E, c_double) if want_E else None))
         return counts, bi.value, bc.value, E
+
+    def ransac_score_ex(self, xi, xj, idx8, thr):
+        """dict(counts, lo, hi, flags, cond, best_iter, best_count, E): certified per-hypothesis inlier counts"""
+        xi, xj = _f64(xi), _f64(xj)
+        idx8 = np.ascontiguousarray(idx8, np.int32)
+        H = idx8.shape[0]
+        counts, lo, hi = np.zeros(H, np.int32), np.zeros(H, np.int32), np.zeros(H, np.int32)
+        flags = np.zeros(H, np.uint8)
+        cond = np.zeros(H)
+        E = np.zeros((H, 3, 3))
+        bi, bc = c_int32(), c_int32()
+        self._chk(self.lib.sfmx_ransac_score_ex(self.h_, _p(xi, c_double), _p(xj, c_double), c_int(xi.shape[0]), _p(idx8, c_int32),
+                                                c_int(H), c_double(thr), _p(counts, c_int32), _p(lo, c_int32), _p(hi, c_int32),
+                                                _p(flags, c_uint8), _p(cond, c_double), byref(bi), byref(bc), _p(E, c_double)))
+        return dict(counts=counts, lo=lo, hi=hi, flags=flags, cond=cond, best_iter=bi.value, best_count=bc.value, E=E)
 
     def sampson_mask(self, xi, xj, E, thr):
         xi, xj, E = _f64(xi), _f64(xj), _f64(E)

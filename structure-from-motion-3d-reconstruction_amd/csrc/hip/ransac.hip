@@ -21,8 +21,15 @@
 //   per block and tested against the block's 8 essential matrices, which sit in SGPRs (uniform loads).
 #include "sfmx_internal.h"
 
+#include <cstdlib>
+#include <vector>
+
 #define HG 16  // lanes per hypothesis
 #define HPW 4  // hypotheses per wave
+// A Jacobi pivot is "nearly tied" when a second off-diagonal entry lies within this relative band of the
+// maximum: rounding differences between this kernel and the reference could then pick different pivots, i.e.
+// follow a different rotation sequence.  Such hypotheses are reported with conditioning 0 (=> exact host E).
+#define PIVOT_TIE_BAND 1e-9
 
 struct Rot { double c, s; };
 // Jacobi rotation of linalg.hpp:153-157 without libm: phi = atan2(y, x)/2 in (-pi/2, pi/2].
@@ -76,7 +83,9 @@ __device__ __forceinline__ Rot half_angle_fast(double y, double x) {
 }
 
 // serial 3x3 Jacobi (linalg.hpp:133-201, N=3) on LDS-resident A3/V3, executed by one lane
-__device__ void jacobi3_lds(double* A, double* V, int sweeps) {
+// returns true if some pivot choice was a near tie (see PIVOT_TIE_BAND)
+__device__ bool jacobi3_lds(double* A, double* V, int sweeps) {
+  bool near_tie = false;
   for (int i = 0; i < 9; i++) V[i] = 0.0;
   V[0] = V[4] = V[8] = 1.0;
   for (int it = 0; it < sweeps; ++it) {
@@ -87,6 +96,8 @@ __device__ void jacobi3_lds(double* A, double* V, int sweeps) {
     if (a02 > big) { big = a02; p = 0; q = 2; }
     if (a12 > big) { big = a12; p = 1; q = 2; }
     if (big < 1e-12) break;
+    const double band = big * (1.0 - PIVOT_TIE_BAND);
+    near_tie |= ((a01 >= band) + (a02 >= band) + (a12 >= band)) > 1;
     const Rot r = half_angle(2.0 * A[p * 3 + q], A[q * 3 + q] - A[p * 3 + p]);
     const double c = r.c, s = r.s;
     for (int k = 0; k < 3; k++) {
@@ -107,6 +118,7 @@ __device__ void jacobi3_lds(double* A, double* V, int sweeps) {
       V[k * 3 + q] = s * vp + c * vq;
     }
   }
+  return near_tie;
 }
 
 __device__ __forceinline__ void unit3(double& x, double& y, double& z) {
@@ -116,14 +128,15 @@ __device__ __forceinline__ void unit3(double& x, double& y, double& z) {
 }
 
 // T:537-607: E -> U diag(s0,s1,0) V^T, executed by one lane; E9 in/out in LDS, scratch: A3,V3 (LDS)
-__device__ void rank2_project(double* E, double* A3, double* V3) {
+// returns the conditioning of the projection: (s1^2 - s2^2) / s0^2 (0 when a 3x3 pivot was nearly tied)
+__device__ double rank2_project(double* E, double* A3, double* V3) {
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) {
       double acc = 0.0;
       for (int k = 0; k < 3; k++) acc += E[3 * k + r] * E[3 * k + c];
       A3[3 * r + c] = acc;
     }
-  jacobi3_lds(A3, V3, 80);
+  const bool tie3 = jacobi3_lds(A3, V3, 80);
   double w[3] = {A3[0], A3[4], A3[8]};
   // eigenvalues ascending (insertion sort as libstdc++ does for N<=16), then singular values descending
   int pe[3] = {0, 1, 2};
@@ -179,6 +192,8 @@ __device__ void rank2_project(double* E, double* A3, double* V3) {
       for (int k = 0; k < 3; k++) acc += US[3 * r + k] * Vd[3 * c + k];  // Vt(k,c) = V(c,k)
       E[3 * r + c] = acc;
     }
+  const double cond = (sd[1] * sd[1] - sd[2] * sd[2]) / (sd[0] * sd[0]);
+  return (tie3 || !(cond > 0.0)) ? 0.0 : cond;
 }
 
 // one step of the 16-lane (value, code) arg-max all-reduce used by the Jacobi pivot search
@@ -200,7 +215,8 @@ struct HypLds {
 };
 
 __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi, const double* __restrict__ xj, int n,
-                                                   const int32_t* __restrict__ idx8, int H, int sweeps, double* __restrict__ E_out) {
+                                                   const int32_t* __restrict__ idx8, int H, int sweeps, double* __restrict__ E_out,
+                                                   double* __restrict__ cond_out) {
   __shared__ HypLds lds[HPW];
   const int lane = threadIdx.x, g = lane / HG, t = lane % HG;
   const int hyp = blockIdx.x * HPW + g;
@@ -252,11 +268,13 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
   }
   const bool third = t < 4;
   bool active = live;
+  bool near_tie = false;  // uniform within the 16-lane group
   for (int it = 0; it < sweeps; ++it) {
     double bv = 0.0;
     int code = 1;  // (0,1): the reference's initial p,q
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
     if (active) {
-      const double v0 = fabs(L.A[own_off[0]]), v1 = fabs(L.A[own_off[1]]), v2 = third ? fabs(L.A[own_off[2]]) : 0.0;
+      v0 = fabs(L.A[own_off[0]]); v1 = fabs(L.A[own_off[1]]); v2 = third ? fabs(L.A[own_off[2]]) : 0.0;
       if (v0 > bv) { bv = v0; code = own_code[0]; }
       if (v1 > bv) { bv = v1; code = own_code[1]; }
       if (v2 > bv) { bv = v2; code = own_code[2]; }
@@ -268,6 +286,13 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
     const int p = code >> 4, q = code & 15;
     if (active && bv < 1e-12) active = false;  // maxv < 1e-12 -> break
     if (!__any(active)) break;
+    {  // a second entry within PIVOT_TIE_BAND of the chosen pivot?
+      const double band = bv * (1.0 - PIVOT_TIE_BAND);
+      const bool mine = active && ((v0 >= band && own_code[0] != code) || (v1 >= band && own_code[1] != code) ||
+                                   (third && v2 >= band && own_code[2] != code));
+      const unsigned long long bal = __ballot(mine);
+      near_tie |= ((bal >> (HG * g)) & 0xffffull) != 0;
+    }
     if (active) {
       // all LDS reads of this rotation are issued together, ahead of the rotation-angle arithmetic
       const int tr = t < 9 ? t : 8;
@@ -305,9 +330,21 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
       const double wi = L.A[i * 9 + i];
       if (wi < wmin) { wmin = wi; col = i; }
     }
+    // conditioning of the choice: gap between the two smallest eigenvalues relative to the largest magnitude
+    double w2 = 0.0, wabs = 0.0;
+    bool have2 = false;
+    for (int i = 0; i < 9; i++) {
+      const double wi = L.A[i * 9 + i];
+      wabs = fmax(wabs, fabs(wi));
+      if (i != col && (!have2 || wi < w2)) { w2 = wi; have2 = true; }
+    }
+    double cond = (w2 - wmin) / wabs;
     for (int r = 0; r < 9; r++) L.E[r] = L.V[r * 9 + col];
-    rank2_project(L.E, L.A3, L.V3);
+    const double cond2 = rank2_project(L.E, L.A3, L.V3);
+    if (!(cond > 0.0) || near_tie) cond = 0.0;  // also NaN
+    cond = fmin(cond, cond2);
     for (int r = 0; r < 9; r++) E_out[(size_t)hyp * 9 + r] = L.E[r];
+    cond_out[hyp] = cond;
   }
 }
 
@@ -329,12 +366,15 @@ __device__ __forceinline__ double sampson_eval(double e0, double e1, double e2, 
 
 #define SC_HB 8
 #define SC_THREADS 256
+// counts[0][h] = #{err < thr}; counts[1][h] = #{err < thr_lo}; counts[2][h] = #{err < thr_hi}  (thr_lo < thr < thr_hi:
+// the band that absorbs the rounding distance between a device hypothesis and the reference's)
 __global__ __launch_bounds__(SC_THREADS) void k_score(const double* __restrict__ xi, const double* __restrict__ xj, int n,
-                                                      const double* __restrict__ E, int H, double thr, int32_t* __restrict__ counts) {
-  __shared__ int part[SC_THREADS / 64][SC_HB];
+                                                      const double* __restrict__ E, int H, double thr, double thr_lo, double thr_hi,
+                                                      int32_t* __restrict__ counts) {
   const int h0 = blockIdx.x * SC_HB;
   const int tid = threadIdx.x;
-  int cnt[SC_HB];
+  // one packed counter per hypothesis: bits 0..19 mid, 20..39 lo, 40..59 hi (n < 2^20 is checked by the host)
+  unsigned long long cnt[SC_HB];
 #pragma unroll
   for (int k = 0; k < SC_HB; k++) cnt[k] = 0;
   const double2* __restrict__ pi = reinterpret_cast<const double2*>(xi);
@@ -346,42 +386,31 @@ __global__ __launch_bounds__(SC_THREADS) void k_score(const double* __restrict__
       const int h = min(h0 + k, H - 1);          // uniform -> scalar loads of E
       const double* e = E + (size_t)h * 9;
       const double err = sampson_eval(e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], a.x, a.y, b.x, b.y);
-      cnt[k] += (err < thr) ? 1 : 0;
+      cnt[k] += ((err < thr) ? 1ull : 0ull) + ((err < thr_lo) ? (1ull << 20) : 0ull) + ((err < thr_hi) ? (1ull << 40) : 0ull);
     }
   }
+  __shared__ unsigned long long part64[SC_THREADS / 64][SC_HB];
 #pragma unroll
   for (int k = 0; k < SC_HB; k++) {
-    int v = cnt[k];
+    unsigned long long v = cnt[k];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((tid & 63) == 0) part[tid >> 6][k] = v;
+    if ((tid & 63) == 0) part64[tid >> 6][k] = v;
   }
   __syncthreads();
   if (tid < SC_HB && h0 + tid < H) {
-    int v = 0;
-    for (int w = 0; w < SC_THREADS / 64; w++) v += part[w][tid];
-    counts[h0 + tid] = v;
+    unsigned long long v = 0;
+    for (int w = 0; w < SC_THREADS / 64; w++) v += part64[w][tid];
+    counts[h0 + tid] = (int32_t)(v & 0xfffffull);
+    counts[H + h0 + tid] = (int32_t)((v >> 20) & 0xfffffull);
+    counts[2 * H + h0 + tid] = (int32_t)((v >> 40) & 0xfffffull);
   }
 }
 
-// argmax over counts with the lowest iteration on ties (the reference's strict '>' at T:673)
-__global__ void k_argmax(const int32_t* __restrict__ counts, int H, int32_t* __restrict__ best2) {
-  __shared__ long long part[4];
-  long long best = -1;
-  for (int h = threadIdx.x; h < H; h += blockDim.x) {
-    const long long key = ((long long)counts[h] << 32) | (long long)(0x7fffffff - h);
-    best = key > best ? key : best;
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    const long long t = __shfl_down(best, o, 64);
-    best = t > best ? t : best;
-  }
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < (int)(blockDim.x >> 6); i++) best = part[i] > best ? part[i] : best;
-    best2[0] = (int32_t)(0x7fffffff - (int32_t)(best & 0xffffffffll));
-    best2[1] = (int32_t)(best >> 32);
-  }
+// rows of exact (host, libm) hypotheses replace the device's before scoring
+__global__ void k_patch_E(double* __restrict__ E, const int32_t* __restrict__ iters, const double* __restrict__ Ex, int m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * 9) return;
+  E[(size_t)iters[i / 9] * 9 + i % 9] = Ex[i];
 }
 
 struct E9 { double e[9]; };
@@ -393,46 +422,144 @@ __global__ void k_sampson_mask(const double* __restrict__ xi, const double* __re
   mask[i] = (err < thr) ? 1 : 0;
 }
 
+// csrc/hip/ransac_exact.cpp (g++, platform libm): eight_point_E of T:609-627 for the listed iterations
+extern "C" void sfmx_exact_eight_point_batch(const double* xi, const double* xj, const int32_t* idx8, const int32_t* iters, int m, double* E_out);
+
+// Relative half-width of the Sampson-error band around thr inside which a device hypothesis' verdict on a point is
+// not trusted, and the conditioning below which a device hypothesis is not used at all.
+static double env_double(const char* name, double dflt) {
+  const char* e = getenv(name);
+  return e ? atof(e) : dflt;
+}
+static double ransac_band() { static const double v = env_double("SFMX_RANSAC_BAND", 1e-6); return v; }
+static double ransac_min_cond() { static const double v = env_double("SFMX_RANSAC_MIN_COND", 1e-5); return v; }
+static inline size_t pad8(size_t v) { return (v + 7) & ~(size_t)7; }
+
 extern "C" {
 
-int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, const int32_t* idx8, int H, double thr,
-                      int32_t* counts_out, int32_t* best_iter, int32_t* best_count, double* E_out) {
-  SFMX_REQUIRE(c, c && xi && xj && idx8 && n >= 8 && H > 0 && best_iter && best_count);
+int sfmx_ransac_score_ex(sfmx_ctx* c, const double* xi, const double* xj, int n, const int32_t* idx8, int H, double thr,
+                         int32_t* counts_out, int32_t* lo_out, int32_t* hi_out, uint8_t* flags_out, double* cond_out,
+                         int32_t* best_iter, int32_t* best_count, double* E_out) {
+  SFMX_REQUIRE(c, c && xi && xj && idx8 && n >= 8 && n < (1 << 20) && H > 0 && best_iter && best_count);
   const size_t pb = (size_t)n * 16, ib = (size_t)H * 32;
-  // one device slab [xi pb][xj pb][idx8 ib] filled by ONE transfer from the pinned staging slab
-  SFMX_HIP(c, c->d[0].ensure(2 * pb + ib));
+  // ---- octets with a repeated index (sampling is with replacement, T:665): their AtA has a null space of dimension
+  // >= 2 and the reference's E is whatever its libm Jacobi lands on -- derived exactly on the host, while the device
+  // builds the other hypotheses, and patched into the hypothesis buffer before scoring.
+  std::vector<int32_t> exact_it;
+  for (int h = 0; h < H; h++) {
+    const int32_t* o = idx8 + (size_t)8 * h;
+    bool rep = false;
+    for (int a = 0; a < 8; a++) {
+      if (o[a] < 0 || o[a] >= n) return sfmx_fail(c, SFMX_ERR_INVALID, "idx8 out of range", hipSuccess);
+      for (int b = a + 1; b < 8; b++) rep |= (o[a] == o[b]);
+    }
+    if (rep) exact_it.push_back(h);
+  }
+  // one device slab [xi pb][xj pb][idx8 ib] filled by ONE transfer from the pinned staging slab; the staging slab
+  // also holds the patch area [iters m*4, padded to 8][E m*72]
+  const size_t in_bytes = 2 * pb + ib, patch_cap = (size_t)H * 76 + 16;
+  const size_t cnt_bytes = pad8((size_t)H * 12);  // [mid H][lo H][hi H] int32, then [cond H] f64
+  SFMX_HIP(c, c->d[0].ensure(in_bytes));
+  SFMX_HIP(c, c->d[1].ensure(patch_cap));
   SFMX_HIP(c, c->d[3].ensure((size_t)H * 72));
-  SFMX_HIP(c, c->d[4].ensure((size_t)H * 4 + 64));   // [counts H*4][best_iter, best_count]
+  SFMX_HIP(c, c->d[4].ensure(cnt_bytes + (size_t)H * 8));
   SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
-  SFMX_HIP(c, c->h[0].ensure(2 * pb + ib));
-  SFMX_HIP(c, c->h[1].ensure((size_t)H * 4 + 64));
+  SFMX_HIP(c, c->h[0].ensure(in_bytes + patch_cap));
+  SFMX_HIP(c, c->h[1].ensure(cnt_bytes + (size_t)H * 8));
   char* hin = c->h[0].as<char>();
   memcpy(hin, xi, pb);
   memcpy(hin + pb, xj, pb);
   memcpy(hin + 2 * pb, idx8, ib);
-  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, hin, 2 * pb + ib, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->d[0].p, hin, in_bytes, hipMemcpyHostToDevice, c->stream));
   c->resident_points = n;
   const double* d_xi = c->d[0].as<double>();
   const double* d_xj = reinterpret_cast<const double*>(c->d[0].as<char>() + pb);
   const int32_t* d_idx = reinterpret_cast<const int32_t*>(c->d[0].as<char>() + 2 * pb);
-  int32_t* d_best = c->d[4].as<int32_t>() + H;
+  int32_t* d_cnt = c->d[4].as<int32_t>();
+  double* d_cond = reinterpret_cast<double*>(c->d[4].as<char>() + cnt_bytes);
+  double* d_E = c->d[3].as<double>();
+  const double band = ransac_band(), thr_lo = thr * (1.0 - band), thr_hi = thr * (1.0 + band);
   KernelTimer t(c);
   t.start();
-  k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(d_xi, d_xj, n, d_idx, H, 120, c->d[3].as<double>());
-  k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, c->d[3].as<double>(), H, thr, c->d[4].as<int32_t>());
-  k_argmax<<<1, 256, 0, c->stream>>>(c->d[4].as<int32_t>(), H, d_best);
+  k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(d_xi, d_xj, n, d_idx, H, 120, d_E, d_cond);
+  SFMX_HIP(c, hipGetLastError());
+  // exact E of the listed iterations -> staging patch area -> d[1]; returns the device pointer of the m x 9 block
+  char* hpatch = hin + in_bytes;
+  auto upload_exact = [&](const std::vector<int32_t>& its, const double** d_rows) -> int {
+    const int m = (int)its.size();
+    const size_t ioff = pad8((size_t)m * 4);
+    memcpy(hpatch, its.data(), (size_t)m * 4);
+    sfmx_exact_eight_point_batch(xi, xj, idx8, its.data(), m, reinterpret_cast<double*>(hpatch + ioff));
+    SFMX_HIP(c, hipMemcpyAsync(c->d[1].p, hpatch, ioff + (size_t)m * 72, hipMemcpyHostToDevice, c->stream));
+    *d_rows = reinterpret_cast<const double*>(c->d[1].as<char>() + ioff);
+    return SFMX_OK;
+  };
+  if (!exact_it.empty()) {  // overlaps with k_hypotheses (the host part) and is ordered behind it (the copy + scatter)
+    const double* d_rows = nullptr;
+    const int rc = upload_exact(exact_it, &d_rows);
+    if (rc != SFMX_OK) return rc;
+    const int m = (int)exact_it.size();
+    k_patch_E<<<(m * 9 + 255) / 256, 256, 0, c->stream>>>(d_E, c->d[1].as<int32_t>(), d_rows, m);
+  }
+  k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, d_E, H, thr, thr_lo, thr_hi, d_cnt);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
-  int32_t best2[2] = {0, 0};
-  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, c->d[4].p, (size_t)H * 4 + 8, hipMemcpyDeviceToHost, c->stream));
-  if (E_out) SFMX_HIP(c, hipMemcpyAsync(E_out, c->d[3].p, (size_t)H * 72, hipMemcpyDeviceToHost, c->stream));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, c->d[4].p, cnt_bytes + (size_t)H * 8, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   t.collect();
-  if (counts_out) memcpy(counts_out, c->h[1].p, (size_t)H * 4);
-  memcpy(best2, c->h[1].as<char>() + (size_t)H * 4, 8);
-  *best_iter = best2[0];
-  *best_count = best2[1];
+  int32_t* h_cnt = c->h[1].as<int32_t>();
+  const double* h_cond = reinterpret_cast<const double*>(c->h[1].as<char>() + cnt_bytes);
+  std::vector<uint8_t> exact((size_t)H, 0);
+  for (int32_t h : exact_it) exact[(size_t)h] = 1;
+  // ---- ill-conditioned device hypotheses (eigenvalue gap, rank-2 gap, nearly tied pivot): second, rare round --
+  // exact E on the host, scored as a compact batch, rows and counts patched in
+  std::vector<int32_t> redo;
+  const double min_cond = ransac_min_cond();
+  for (int h = 0; h < H; h++)
+    if (!exact[(size_t)h] && !(h_cond[h] >= min_cond)) redo.push_back(h);
+  if (!redo.empty()) {
+    const int m = (int)redo.size();
+    const double* d_rows = nullptr;
+    const int rc = upload_exact(redo, &d_rows);
+    if (rc != SFMX_OK) return rc;
+    SFMX_HIP(c, c->d[2].ensure((size_t)m * 12 + 64));
+    SFMX_HIP(c, c->h[2].ensure((size_t)m * 12 + 64));
+    int32_t* d_cnt2 = c->d[2].as<int32_t>();
+    k_patch_E<<<(m * 9 + 255) / 256, 256, 0, c->stream>>>(d_E, c->d[1].as<int32_t>(), d_rows, m);
+    k_score<<<(m + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, d_rows, m, thr, thr_lo, thr_hi, d_cnt2);
+    SFMX_HIP(c, hipGetLastError());
+    SFMX_HIP(c, hipMemcpyAsync(c->h[2].p, d_cnt2, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipStreamSynchronize(c->stream));
+    const int32_t* c2 = c->h[2].as<int32_t>();
+    for (int k = 0; k < m; k++) {
+      h_cnt[redo[(size_t)k]] = c2[k];
+      exact[(size_t)redo[(size_t)k]] = 1;
+    }
+  }
+  // exact hypotheses: the count is the reference's (the Sampson arithmetic is bit-exact for a given E)
+  for (int h = 0; h < H; h++)
+    if (exact[(size_t)h]) h_cnt[H + h] = h_cnt[2 * H + h] = h_cnt[h];
+  if (E_out) {
+    SFMX_HIP(c, hipMemcpyAsync(E_out, d_E, (size_t)H * 72, hipMemcpyDeviceToHost, c->stream));
+    SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  if (counts_out) memcpy(counts_out, h_cnt, (size_t)H * 4);
+  if (lo_out) memcpy(lo_out, h_cnt + H, (size_t)H * 4);
+  if (hi_out) memcpy(hi_out, h_cnt + 2 * H, (size_t)H * 4);
+  if (flags_out) memcpy(flags_out, exact.data(), (size_t)H);
+  if (cond_out) memcpy(cond_out, h_cond, (size_t)H * 8);
+  // argmax with the LOWEST iteration on ties (the reference's strict '>' at T:673)
+  int32_t bi = 0, bc = h_cnt[0];
+  for (int h = 1; h < H; h++)
+    if (h_cnt[h] > bc) { bc = h_cnt[h]; bi = h; }
+  *best_iter = bi;
+  *best_count = bc;
   return SFMX_OK;
+}
+
+int sfmx_ransac_score(sfmx_ctx* c, const double* xi, const double* xj, int n, const int32_t* idx8, int H, double thr,
+                      int32_t* counts_out, int32_t* best_iter, int32_t* best_count, double* E_out) {
+  return sfmx_ransac_score_ex(c, xi, xj, n, idx8, H, thr, counts_out, nullptr, nullptr, nullptr, nullptr, best_iter, best_count, E_out);
 }
 
 // xi == xj == NULL reuses the correspondences left in HBM by the preceding sfmx_ransac_score call

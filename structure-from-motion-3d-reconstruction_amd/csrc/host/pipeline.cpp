@@ -664,9 +664,10 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
   if (iters <= 0) return std::nullopt;
   if (clk) clk->r_pre += since(t0);
   const auto tg0 = Clock::now();
-  std::vector<std::int32_t> counts((size_t)iters);
+  std::vector<std::int32_t> counts((size_t)iters), lo((size_t)iters), hi((size_t)iters);
   std::int32_t best_iter = -1, best_count = 0;
-  check(ctx, sfmx_ransac_score(ctx, xi.data(), xj.data(), n, idx8.data(), iters, thr, counts.data(), &best_iter, &best_count, nullptr),
+  check(ctx, sfmx_ransac_score_ex(ctx, xi.data(), xj.data(), n, idx8.data(), iters, thr, counts.data(), lo.data(), hi.data(), nullptr, nullptr,
+                                  &best_iter, &best_count, nullptr),
         "ransac_score");
   if (clk) {
     clk->ransac_kernel_us += sfmx_last_kernel_us(ctx);
@@ -675,21 +676,16 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
     clk->r_gpu += since(tg0);
   }
   const auto tv0 = Clock::now();
-  // Device hypotheses rank the iterations; the winner's E is re-derived with the platform libm (so it
-  // is the reference's E bit for bit) and its mask recomputed from that E on the device.
-  //
-  // Verification set: iterations whose device count is within 2 of the maximum are "near ties"; the
-  // reference's winner is the LOWEST iteration with the maximal exact count (strict '>' at T:673).
-  //  * few near ties (<= 24): all of them are verified exactly;
-  //  * many (clean data: thousands of hypotheses reach the same maximal count): the device winner b
-  //    and every near tie BEFORE b are verified; later iterations could only win with an exact count
-  //    strictly above exact(b), i.e. if the device had under-counted them -- if exact(b) turns out to
-  //    differ from its device count at all, every near tie is verified (slow path, not seen in tests).
+  // The library reports, per iteration, a count and certified bounds lo <= reference count <= hi (include/sfmx.h):
+  // lo == hi where the hypothesis is the exact host one (repeated-index / ill-conditioned octets) or where no point
+  // lies inside the rounding band around thr.  The reference's winner is the LOWEST iteration with the maximal count
+  // (strict '>' at T:673); only iterations with hi >= max(lo) can be it.  Of those, the uncertain ones (lo < hi) are
+  // re-derived exactly here -- E with the platform libm, mask from that E on the device -- and so is the winner, whose
+  // E and mask are what leaves this function.
   std::optional<RelPose> result;
-  if (best_count > 0) {
-    std::vector<int> near;
-    for (int it = 0; it < iters; ++it)
-      if (counts[(size_t)it] >= best_count - 2 && counts[(size_t)it] > 0) near.push_back(it);
+  int best_lo = 0, best_hi = 0;
+  for (int it = 0; it < iters; ++it) { best_lo = std::max(best_lo, lo[(size_t)it]); best_hi = std::max(best_hi, hi[(size_t)it]); }
+  if (best_hi > 0 && best_hi >= min_inliers) {
     int win_iter = -1, win_count = -1;
     Mat3 winE;
     std::vector<std::uint8_t> mask((size_t)n), win_mask;
@@ -706,18 +702,24 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
       }
       return cnt;
     };
-    if (near.size() <= 24) {
-      for (int it : near) verify(it);
-    } else {
-      bool device_exact = true;
-      for (int it : near) {
-        if (it > best_iter) break;
-        const int cnt = verify(it);
-        if (it == best_iter && cnt != best_count) device_exact = false;
+    // pass 1: exact counts of the uncertain candidates; the best certain candidate (count, lowest iteration)
+    int cert_iter = -1, cert_count = -1;
+    for (int it = 0; it < iters; ++it) {
+      if (hi[(size_t)it] < best_lo || hi[(size_t)it] <= 0) continue;
+      if (lo[(size_t)it] < hi[(size_t)it]) verify(it);
+      else if (counts[(size_t)it] > cert_count) { cert_count = counts[(size_t)it]; cert_iter = it; }
+    }
+    // pass 2: the best certain candidate beats (or ties earlier than) every verified one?  Then it is the winner and
+    // needs its exact E and mask; its exact count must equal the certified one.
+    if (cert_iter >= 0 && (cert_count > win_count || (cert_count == win_count && cert_iter < win_iter))) {
+      const int cnt = verify(cert_iter);
+      if (cnt != cert_count) {
+        // A certificate did not hold (never observed).  Parity first: fall back to exact counts of every candidate.
+        if (clk) clk->ransac_cert_misses++;
+        win_iter = -1; win_count = -1;
+        for (int it = 0; it < iters; ++it)
+          if (hi[(size_t)it] >= best_lo - 4 && hi[(size_t)it] > 0) verify(it);
       }
-      if (!device_exact)
-        for (int it : near)
-          if (it > best_iter) verify(it);
     }
     if (clk) clk->r_verify += since(tv0);
     const auto td0 = Clock::now();
@@ -987,7 +989,7 @@ void StageClock::add(const StageClock& o) {
   tri_insert += o.tri_insert;
   klt_kernel_us += o.klt_kernel_us; ransac_kernel_us += o.ransac_kernel_us; ba_kernel_us += o.ba_kernel_us; shi_kernel_us += o.shi_kernel_us;
   lk_steps += o.lk_steps; tracks_in += o.tracks_in; ransac_calls += o.ransac_calls; ransac_points += o.ransac_points; ba_calls += o.ba_calls;
-  ba_iters += o.ba_iters; klt_calls += o.klt_calls; ransac_verified += o.ransac_verified; shi_fallbacks += o.shi_fallbacks;
+  ba_iters += o.ba_iters; klt_calls += o.klt_calls; ransac_verified += o.ransac_verified; ransac_cert_misses += o.ransac_cert_misses; shi_fallbacks += o.shi_fallbacks;
   shi_calls += o.shi_calls; shi_memo_hits += o.shi_memo_hits; shi_prefetched += o.shi_prefetched;
   shi_wait += o.shi_wait; setup += o.setup;
   pf_busy += o.pf_busy; pf_gpu += o.pf_gpu; pf_replay += o.pf_replay; lane_b_busy += o.lane_b_busy; lane_c_busy += o.lane_c_busy;
@@ -1460,6 +1462,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   if (lane_c) {
     lane_clk.ransac += lane_c_clk.ransac; lane_clk.ransac_kernel_us += lane_c_clk.ransac_kernel_us; lane_clk.ransac_calls += lane_c_clk.ransac_calls;
     lane_clk.ransac_points += lane_c_clk.ransac_points; lane_clk.ransac_verified += lane_c_clk.ransac_verified;
+    lane_clk.ransac_cert_misses += lane_c_clk.ransac_cert_misses;
     lane_clk.r_pre += lane_c_clk.r_pre; lane_clk.r_gpu += lane_c_clk.r_gpu; lane_clk.r_verify += lane_c_clk.r_verify; lane_clk.r_decomp += lane_c_clk.r_decomp;
     clk.klt += lane_c_clk.klt; clk.klt_kernel_us += lane_c_clk.klt_kernel_us; clk.lk_steps += lane_c_clk.lk_steps;
     clk.tracks_in += lane_c_clk.tracks_in; clk.klt_calls += lane_c_clk.klt_calls;
@@ -1468,6 +1471,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     clk.ba += lane_clk.ba; clk.ba_kernel_us += lane_clk.ba_kernel_us; clk.ba_calls += lane_clk.ba_calls; clk.ba_iters += lane_clk.ba_iters;
     clk.ransac += lane_clk.ransac; clk.ransac_kernel_us += lane_clk.ransac_kernel_us; clk.ransac_calls += lane_clk.ransac_calls;
     clk.ransac_points += lane_clk.ransac_points; clk.ransac_verified += lane_clk.ransac_verified;
+    clk.ransac_cert_misses += lane_clk.ransac_cert_misses;
     clk.r_pre += lane_clk.r_pre; clk.r_gpu += lane_clk.r_gpu; clk.r_verify += lane_clk.r_verify; clk.r_decomp += lane_clk.r_decomp;
   }
   out.log = so.str();
@@ -1544,6 +1548,7 @@ struct sfmx_pipeline_stats {
   double sec_shi_wait, sec_setup, sec_wall;
   double sec_pf_busy, sec_pf_gpu, sec_pf_replay, sec_lane_b_busy, sec_lane_c_busy, sec_join_wait, sec_ba_gather;
   double sec_m_step, sec_m_ransac, sec_m_kf, sec_feed_wait;
+  unsigned long long ransac_cert_misses;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -1590,7 +1595,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
                                    c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait, c.setup, wall,
                                    c.pf_busy, c.pf_gpu, c.pf_replay, c.lane_b_busy, c.lane_c_busy, c.join_wait, c.ba_gather,
-                                   c.m_step, c.m_ransac, c.m_kf, c.feed_wait};
+                                   c.m_step, c.m_ransac, c.m_kf, c.feed_wait, c.ransac_cert_misses};
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {
@@ -1610,6 +1615,90 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
 
 // frees the helper contexts kept for reuse by later sfmx_pipeline_run calls
 void sfmx_host_release_contexts() { sfmx_host::ContextPool::instance().clear(); }
+
+// find_E_ransac seam (T:646-761) on its own, for the parity tests: 1 = pose found, 0 = none (T:648, T:678), < 0 = -status
+int sfmx_host_find_E_ransac(sfmx_ctx* ctx, const double* K9, const double* pi, const double* pj, int n, int iters, double thr, int min_inliers,
+                            double* R9, double* t3, int* inliers, int* n_inl, int* best_iter) {
+  using namespace sfmx_host;
+  try {
+    Mat3 K;
+    std::memcpy(K.a, K9, 72);
+    std::vector<V2> a((size_t)std::max(n, 0)), b((size_t)std::max(n, 0));
+    for (int i = 0; i < n; i++) { a[(size_t)i] = {pi[2 * i], pi[2 * i + 1]}; b[(size_t)i] = {pj[2 * i], pj[2 * i + 1]}; }
+    const auto r = find_E_ransac_gpu(ctx, K, a, b, iters, thr, min_inliers, nullptr);
+    *n_inl = 0;
+    if (!r) return 0;
+    std::memcpy(R9, r->R_ji.a, 72);
+    t3[0] = r->t_ji.x; t3[1] = r->t_ji.y; t3[2] = r->t_ji.z;
+    *n_inl = (int)r->inliers.size();
+    for (size_t i = 0; i < r->inliers.size(); i++) inliers[i] = r->inliers[i];
+    if (best_iter) *best_iter = r->best_iter;
+    return 1;
+  } catch (const SfmxFailure& e) {
+    return -e.status;
+  } catch (const std::exception&) {
+    return -SFMX_ERR_INVALID;
+  }
+}
+
+// KLTTracker seam (T:307-400) on its own, one image per step, for the parity tests against the reference's tracker state
+struct sfmx_host_tracker {
+  struct OneImage : sfmx_host::FrameSource {
+    const std::uint8_t* pix = nullptr;
+    int w = 0, h = 0;
+    int count() const override { return 1 << 30; }
+    int width() const override { return w; }
+    int height() const override { return h; }
+    void load(sfmx_ctx* ctx, int, sfmx_pyramid* pyr) override {
+      if (sfmx_pyramid_upload(ctx, pyr, pix) != SFMX_OK) throw std::runtime_error("pyramid_upload");
+    }
+  } src;
+  std::unique_ptr<sfmx_host::GpuTracker> trk;
+  int frame = 0;
+};
+void* sfmx_host_tracker_create(sfmx_ctx* ctx, int w, int h, int max_tracks, int min_tracks, double quality, int min_distance, int levels,
+                               int radius, int iters, double fb) {
+  try {
+    auto t = std::make_unique<sfmx_host_tracker>();
+    t->src.w = w; t->src.h = h;
+    sfmx_host::LKConfig c;
+    c.max_tracks = max_tracks; c.min_tracks = min_tracks; c.quality = quality; c.min_distance = min_distance;
+    c.pyr_levels = levels; c.win_radius = radius; c.iters = iters; c.fb_thresh = fb;
+    t->trk = std::make_unique<sfmx_host::GpuTracker>(ctx, c, w, h, 0, nullptr);
+    return t.release();
+  } catch (...) {
+    return nullptr;
+  }
+}
+void sfmx_host_tracker_destroy(void* h) { delete static_cast<sfmx_host_tracker*>(h); }
+// StepOut of KLTTracker::step (T:340-391): returns the number of survivors (prev/cur [n][2], ids [n]), < 0 on error
+int sfmx_host_tracker_step(void* h, const std::uint8_t* pix, double* prev_xy, double* cur_xy, int* ids, int cap) {
+  auto* t = static_cast<sfmx_host_tracker*>(h);
+  try {
+    t->src.pix = pix;
+    const sfmx_host::StepOut o = t->trk->step(t->src, t->frame++);
+    const int n = (int)o.ids.size();
+    if (n > cap) return -SFMX_ERR_INVALID;
+    for (int i = 0; i < n; i++) {
+      prev_xy[2 * i] = o.prev_pts[(size_t)i].x; prev_xy[2 * i + 1] = o.prev_pts[(size_t)i].y;
+      cur_xy[2 * i] = o.cur_pts[(size_t)i].x; cur_xy[2 * i + 1] = o.cur_pts[(size_t)i].y;
+      ids[i] = o.ids[(size_t)i];
+    }
+    return n;
+  } catch (const sfmx_host::SfmxFailure& e) {
+    return -e.status;
+  } catch (const std::exception&) {
+    return -SFMX_ERR_INVALID;
+  }
+}
+int sfmx_host_tracker_tracks(void* h, double* xy, int* ids, int cap) {  // KLTTracker::tracks() (T:393)
+  auto* t = static_cast<sfmx_host_tracker*>(h);
+  const auto& tr = t->trk->tracks();
+  const int n = (int)tr.size();
+  if (n > cap) return -SFMX_ERR_INVALID;
+  for (int i = 0; i < n; i++) { xy[2 * i] = tr[(size_t)i].p.x; xy[2 * i + 1] = tr[(size_t)i].p.y; ids[i] = tr[(size_t)i].id; }
+  return n;
+}
 
 // host-side math self-checks used by the CPU test-suite (no device involved)
 // Iteration order of an unordered_map<int,int> filled (and partly erased) with `keys`: default allocator vs the bump

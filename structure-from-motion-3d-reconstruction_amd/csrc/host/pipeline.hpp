@@ -70,6 +70,7 @@ struct StageClock {
   double r_pre = 0, r_gpu = 0, r_verify = 0, r_decomp = 0, tri_iter = 0, tri_solve = 0, tri_insert = 0;
   double klt_kernel_us = 0, ransac_kernel_us = 0, ba_kernel_us = 0, shi_kernel_us = 0;
   std::uint64_t lk_steps = 0, tracks_in = 0, ransac_calls = 0, ransac_points = 0, ba_calls = 0, ba_iters = 0, klt_calls = 0;
+  std::uint64_t ransac_cert_misses = 0;  // a certified inlier count that did not hold (parity fallback taken)
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
   double shi_wait = 0, setup = 0;
   double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_b_busy = 0, lane_c_busy = 0, join_wait = 0, ba_gather = 0;

@@ -37,7 +37,7 @@ class PipelineStats(ctypes.Structure):
                 ("sec_setup", c_double), ("sec_wall", c_double), ("sec_pf_busy", c_double), ("sec_pf_gpu", c_double),
                 ("sec_pf_replay", c_double), ("sec_lane_b_busy", c_double), ("sec_lane_c_busy", c_double),
                 ("sec_join_wait", c_double), ("sec_ba_gather", c_double), ("sec_m_step", c_double), ("sec_m_ransac", c_double),
-                ("sec_m_kf", c_double), ("sec_feed_wait", c_double)]
+                ("sec_m_kf", c_double), ("sec_feed_wait", c_double), ("ransac_cert_misses", c_ulonglong)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -91,3 +91,68 @@ def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=No
     if rc != capi.SFMX_OK:
         raise capi.SfmxError(rc, text.strip())
     return dict(log=text, stats=st.asdict(), centres=centres[:st.n_keyframes].copy())
+
+
+def find_E_ransac(ctx: capi.Context, K, pi, pj, iters: int, thr: float, min_inliers: int):
+    """The find_E_ransac seam (T:646-761) of the host library on its own: dict(ok, R, t, inliers, best_iter)."""
+    lib = load_host_library()
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    pi = np.ascontiguousarray(pi, np.float64)
+    pj = np.ascontiguousarray(pj, np.float64)
+    n = pi.shape[0]
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    inl = np.zeros(max(n, 1), np.int32)
+    n_inl, best = c_int(0), c_int(-1)
+    dp = POINTER(c_double)
+    rc = lib.sfmx_host_find_E_ransac(ctx.h_, K.ctypes.data_as(dp), pi.ctypes.data_as(dp), pj.ctypes.data_as(dp), c_int(n), c_int(iters),
+                                     c_double(thr), c_int(min_inliers), R.ctypes.data_as(dp), t.ctypes.data_as(dp),
+                                     inl.ctypes.data_as(POINTER(c_int)), byref(n_inl), byref(best))
+    if rc < 0:
+        raise capi.SfmxError(-rc, "find_E_ransac")
+    return dict(ok=rc, R=R, t=t, inliers=inl[:n_inl.value].copy(), best_iter=best.value)
+
+
+class Tracker:
+    """The KLTTracker seam (T:307-400) of the host library on its own: step(image) -> (prev, cur, ids); tracks()."""
+
+    def __init__(self, ctx: capi.Context, w: int, h: int, max_tracks=2200, min_tracks=900, quality=0.01, min_distance=8, levels=3,
+                 radius=5, iters=10, fb=1.0):
+        self.lib = load_host_library()
+        self.cap, self.w, self.h = max_tracks, w, h
+        self.lib.sfmx_host_tracker_create.restype = c_void_p
+        self.h_ = c_void_p(self.lib.sfmx_host_tracker_create(ctx.h_, c_int(w), c_int(h), c_int(max_tracks), c_int(min_tracks),
+                                                              c_double(quality), c_int(min_distance), c_int(levels), c_int(radius),
+                                                              c_int(iters), c_double(fb)))
+        if not self.h_:
+            raise capi.SfmxError(capi.SFMX_ERR_INVALID, "tracker_create")
+
+    def step(self, img: np.ndarray):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.h, self.w)
+        prev, cur = np.zeros((self.cap, 2)), np.zeros((self.cap, 2))
+        ids = np.zeros(self.cap, np.int32)
+        dp = POINTER(c_double)
+        n = self.lib.sfmx_host_tracker_step(self.h_, img.ctypes.data_as(c_void_p), prev.ctypes.data_as(dp), cur.ctypes.data_as(dp),
+                                            ids.ctypes.data_as(POINTER(c_int)), c_int(self.cap))
+        if n < 0:
+            raise capi.SfmxError(-n, "tracker_step")
+        return prev[:n].copy(), cur[:n].copy(), ids[:n].copy()
+
+    def tracks(self):
+        xy = np.zeros((self.cap, 2))
+        ids = np.zeros(self.cap, np.int32)
+        n = self.lib.sfmx_host_tracker_tracks(self.h_, xy.ctypes.data_as(POINTER(c_double)), ids.ctypes.data_as(POINTER(c_int)), c_int(self.cap))
+        if n < 0:
+            raise capi.SfmxError(-n, "tracker_tracks")
+        return xy[:n].copy(), ids[:n].copy()
+
+    def close(self):
+        if self.h_:
+            self.lib.sfmx_host_tracker_destroy(self.h_)
+            self.h_ = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

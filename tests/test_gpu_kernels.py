@@ -110,6 +110,59 @@ def test_klt_synthetic_vs_oracle(ctx):
     assert keep.sum() > 100  # the case must actually track something
 
 
+def test_tracker_step_vs_reference_goldens(ctx, golden):
+    """KLTTracker::{reset,step} (T:322-391) through the host seam against the state the compiled reference produced
+    (trk_* in hotpath.npz): StepOut ids / prev / cur of every frame and the live tracks after replenishment."""
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    c = golden["trk_cfg"]
+    imgs = golden["trk_images"]
+    T = pipe.Tracker(ctx, imgs.shape[2], imgs.shape[1], int(c[0]), int(c[1]), float(c[2]), int(c[3]), int(c[4]), int(c[5]), int(c[6]), float(c[7]))
+    for f in range(5):
+        prev, cur, ids = T.step(imgs[f])
+        txy, tid = T.tracks()
+        assert np.array_equal(ids, golden[f"trk_ids_{f}"]), f
+        H.assert_bits_equal(prev, golden[f"trk_prev_{f}"], f"prev {f}")
+        H.assert_bits_equal(cur, golden[f"trk_cur_{f}"], f"cur {f}")
+        assert np.array_equal(tid, golden[f"trk_tid_{f}"]), f
+        H.assert_bits_equal(txy, golden[f"trk_txy_{f}"], f"tracks {f}")
+    T.close()
+
+
+def test_c5_image_size_1920x1080_vs_oracle(ctx):
+    """BASELINE config 5's image size: pyramid, Shi-Tomasi score map, and the tracker seam (detector pick + KLT fwd/bwd +
+    replenish) on 1920x1080 frames with 5000 tracks, against the oracle."""
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    seq = synth.make_sequence(3, 1920, 1080, 0.003, n_blobs=120000, seed=3, shell_scale=2.2)  # the reference LK overshoots: sub-pixel flow only
+    a = seq["images"][0]
+    pyr = ctx.pyramid(a, 4)
+    cur = a
+    for l in (1, 2, 3):
+        cur = H.downsample2(O, "orc", cur)
+        assert np.array_equal(pyr.level(l), cur), f"level {l}"
+    score, mx = ctx.shi_score(pyr)
+    exp = np.zeros(a.shape)
+    O.call("orc_shi_score", None, H.u8(a), a.shape[1], a.shape[0], exp)
+    H.assert_bits_equal(score, exp, "1080p score map")
+    assert mx == exp.max()
+    kw = dict(max_tracks=5000, min_tracks=4800, quality=0.01, min_distance=8, levels=3, radius=5, iters=10, fb=1.0)
+    Tg = pipe.Tracker(ctx, 1920, 1080, **kw)
+    To = H.Tracker(O, "orc", **kw)
+    for f in range(3):
+        gp, gc, gi = Tg.step(seq["images"][f])
+        op, oc, oi = To.step(seq["images"][f])
+        assert np.array_equal(gi, oi), f
+        H.assert_bits_equal(gp, op, f"prev {f}")
+        H.assert_bits_equal(gc, oc, f"cur {f}")
+        gxy, gid = Tg.tracks()
+        oxy, oid = To.tracks()
+        assert np.array_equal(gid, oid), f
+        H.assert_bits_equal(gxy, oxy, f"tracks {f}")
+        assert len(gid) >= 4000, len(gid)
+    assert len(gi) >= 3000  # the frames must really be tracked, not only re-seeded
+    Tg.close()
+    To.close()
+
+
 def test_klt_empty_and_radius_limits(ctx, golden):
     pa, pb = ctx.pyramid(golden["klt_a"], 3), ctx.pyramid(golden["klt_b"], 3)
     fwd, back, keep, steps = ctx.klt_track(pa, pb, np.zeros((0, 2)))
@@ -123,40 +176,96 @@ def test_klt_empty_and_radius_limits(ctx, golden):
         ctx.klt_track(pa, pb, pts, 3, 8, 3, 1.0)
 
 
+def _check_certified(res, Eref, cref, what):
+    """Contract of sfmx_ransac_score_ex (include/sfmx.h) against the reference's hypotheses / counts of EVERY iteration:
+    exact rows are the reference's E bit for bit, every count equals the reference's, and it lies inside [lo, hi]."""
+    ex = res["flags"].astype(bool)
+    H.assert_bits_equal(res["E"][ex], Eref[ex], f"{what}: exact (host libm) hypotheses")
+    assert np.array_equal(res["counts"], cref), (what, np.nonzero(res["counts"] != cref)[0][:10])
+    assert np.all(res["lo"] <= cref) and np.all(cref <= res["hi"]), what
+    assert np.array_equal(res["lo"][ex], cref[ex]) and np.array_equal(res["hi"][ex], cref[ex]), what
+    best = int(np.argmax(cref))  # first maximum == lowest iteration on ties (T:673)
+    assert (res["best_iter"], res["best_count"]) == (best, int(cref[best])), what
+    # device hypotheses: same vector as the reference's up to rounding / the conditioning the library tolerates
+    scale = np.abs(Eref).max(axis=(1, 2))
+    err = np.abs(res["E"] - Eref).max(axis=(1, 2)) / scale
+    assert np.all(err[~ex] < 1e-8), (what, err[~ex].max())
+    return ex
+
+
 def test_ransac_counts_and_mask(ctx, golden):
     xi, xj, idx8 = golden["tv_xi"], golden["tv_xj"], golden["tv_idx8"]
-    counts, bi, bc, E = ctx.ransac_score(xi, xj, idx8, 1e-3, want_E=True)
-    # reference hypotheses (libm Jacobi) and their counts
+    res = ctx.ransac_score_ex(xi, xj, idx8, 1e-3)
+    # reference hypotheses (libm Jacobi) and their counts, every octet (incl. the repeated-index ones)
     Eref = golden["tv_E"]
     cref = np.zeros(len(idx8), np.int32)
     O.call("orc_ransac_counts", None, H.f64(xi), H.f64(xj), len(xi), H.f64(Eref), len(idx8), 1e-3, cref)
-    nondeg = np.array([len(set(r)) == 8 for r in idx8])
-    # device E equals the reference E up to the rounding of the algebraic Jacobi rotation (sign is fixed by the algorithm)
-    scale = np.abs(Eref).max(axis=(1, 2))
-    err = np.abs(E - Eref).max(axis=(1, 2)) / scale
-    assert np.all(err[nondeg] < 1e-9), err[nondeg].max()
-    assert np.array_equal(counts[nondeg], cref[nondeg])
-    best = int(np.argmax(cref))  # first maximum == lowest iteration on ties
-    if nondeg[best] and cref[nondeg].max() == cref.max():
-        assert (bi, bc) == (best, int(cref[best]))
+    ex = _check_certified(res, Eref, cref, "golden tv")
+    deg = np.array([len(set(r)) < 8 for r in idx8])
+    assert deg.any() and np.all(ex[deg]), "repeated-index octets must be scored with the exact host hypothesis"
+    counts, bi, bc, _ = ctx.ransac_score(xi, xj, idx8, 1e-3)  # the plain entry point is the same computation
+    assert np.array_equal(counts, cref) and (bi, bc) == (res["best_iter"], res["best_count"])
     # exact mask for a given E (bit-exact Sampson arithmetic)
-    for k in (0, best):
+    for k in (0, int(np.argmax(cref))):
         mask, cnt = ctx.sampson_mask(xi, xj, Eref[k], 1e-3)
         exp = np.array([H.sampson(O, "orc", Eref[k], xi[i], xj[i]) < 1e-3 for i in range(len(xi))])
         assert np.array_equal(mask.astype(bool), exp) and cnt == exp.sum()
 
 
-def test_ransac_full_call_ranking(ctx, golden):
-    """2500 hypotheses: device ranking must pick the iteration the oracle's find_E_ransac picks."""
+def test_ransac_full_call_every_iteration(ctx, golden):
+    """2500 hypotheses (BASELINE call shape, T:1739): every iteration's count equals the oracle's, the winner is the
+    iteration the oracle's find_E_ransac picks, and the host seam returns its inliers / R / t."""
     K, pi, pj = golden["tv_K"], golden["tv_pi"], golden["tv_pj"]
+    xi, xj = golden["tv_xi"], golden["tv_xj"]
     n = len(pi)
     idx8 = H.uniform_draws(O, "orc", 12345, n, 8 * 2500).reshape(2500, 8)
-    counts, bi, bc, _ = ctx.ransac_score(golden["tv_xi"], golden["tv_xj"], idx8, 1e-3)
+    Eref = np.array([H.eight_point(O, "orc", xi, xj, d) for d in idx8])
+    cref = np.zeros(2500, np.int32)
+    O.call("orc_ransac_counts", None, H.f64(xi), H.f64(xj), n, H.f64(Eref), 2500, 1e-3, cref)
+    res = ctx.ransac_score_ex(xi, xj, idx8, 1e-3)
+    _check_certified(res, Eref, cref, "2500 iterations")
     r = H.find_E_ransac(O, "orc", K, pi, pj, 2500, 1e-3, 60)
-    assert r["ok"] == 1
-    assert bi == r["best_iter"] and bc == len(r["inliers"])
-    mask, cnt = ctx.sampson_mask(golden["tv_xi"], golden["tv_xj"], r["E"], 1e-3)
+    assert r["ok"] == 1 and res["best_iter"] == r["best_iter"] and res["best_count"] == len(r["inliers"])
+    mask, cnt = ctx.sampson_mask(xi, xj, r["E"], 1e-3)
     assert np.array_equal(np.nonzero(mask)[0], r["inliers"])
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    got = pipe.find_E_ransac(ctx, K, pi, pj, 2500, 1e-3, 60)
+    assert got["ok"] == 1 and got["best_iter"] == r["best_iter"] and np.array_equal(got["inliers"], r["inliers"])
+    H.assert_bits_equal(got["R"], r["R"], "R")
+    H.assert_bits_equal(got["t"], r["t"], "t")
+
+
+def test_find_E_ransac_seam_vs_reference_goldens(ctx, golden):
+    """The find_E_ransac seam against what the compiled reference returned (rs_* in hotpath.npz)."""
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    for iters, thr, mi in golden["rs_cases"]:
+        tag = f"{int(iters)}_{int(mi)}"
+        got = pipe.find_E_ransac(ctx, golden["tv_K"], golden["tv_pi"], golden["tv_pj"], int(iters), float(thr), int(mi))
+        assert got["ok"] == int(golden[f"rs_ok_{tag}"][0]), tag
+        if got["ok"]:
+            assert np.array_equal(got["inliers"], golden[f"rs_inl_{tag}"]), tag
+            H.assert_bits_equal(got["R"], golden[f"rs_R_{tag}"], "R " + tag)
+            H.assert_bits_equal(got["t"], golden[f"rs_t_{tag}"], "t " + tag)
+    assert pipe.find_E_ransac(ctx, golden["tv_K"], golden["tv_pi"][:7], golden["tv_pj"][:7], 10, 1e-3, 1)["ok"] == 0  # T:648
+
+
+@pytest.mark.parametrize("kind", ["deg_wins", "deg_ties", "clean_wins"])
+def test_ransac_degenerate_octets(ctx, kind):
+    """tests/golden/ransac_degenerate.npz, generated from the compiled reference: a repeated-index octet is the
+    reference's winner / ties the maximum earlier than a clean one / ties it later (sampling with replacement, T:665;
+    strict '>' at T:673).  Counts of every iteration, winner, inliers, R and t must be the reference's."""
+    g = np.load(os.path.join(H.GOLDEN, "ransac_degenerate.npz"))
+    iters, thr, mi = g[f"{kind}_args"]
+    xi, xj, idx8 = g[f"{kind}_xi"], g[f"{kind}_xj"], g[f"{kind}_idx8"]
+    res = ctx.ransac_score_ex(xi, xj, idx8, float(thr))
+    ex = _check_certified(res, g[f"{kind}_E"], g[f"{kind}_counts"], kind)
+    assert np.all(ex[g[f"{kind}_deg"]])
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    got = pipe.find_E_ransac(ctx, g[f"{kind}_K"], g[f"{kind}_pi"], g[f"{kind}_pj"], int(iters), float(thr), int(mi))
+    assert got["ok"] == 1 and got["best_iter"] == int(g[f"{kind}_best"][0])
+    assert np.array_equal(got["inliers"], g[f"{kind}_inl"])
+    H.assert_bits_equal(got["R"], g[f"{kind}_R"], "R")
+    H.assert_bits_equal(got["t"], g[f"{kind}_t"], "t")
 
 
 @pytest.mark.parametrize("case", [(2, 30), (6, 80), (10, 120)])

@@ -63,6 +63,52 @@ def test_pipeline_640x480_vs_oracle(ctx, tmp_path):
     _same_files(out_g, out_o)
 
 
+def test_bench_workload_47_frames_vs_oracle(ctx, tmp_path):
+    """BASELINE config 2 == the workload bench.py times: 47 frames 640x480, reference default config (synthetic
+    TempleRing-47 stand-in, same generator call and seed as bench.py rank 0).  stdout and all three output files must be
+    byte-equal to the oracle's run: the BA window slides past 6 keyframes, lane joins happen at full image size."""
+    seq = synth.make_sequence(47, 640, 480, 0.3, n_blobs=20000, seed=7)
+    cfg = dict(H.PIPE_DEFAULTS, frames=47)
+    out_g, out_o = str(tmp_path / "gpu"), str(tmp_path / "orc")
+    r = pipe.run(ctx, seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out_g)
+    rc, olog, nk, npnt = H.orc_pipeline_run(seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out_o)
+    assert rc == 0 and nk >= 30 and npnt > 1000, (nk, npnt)
+    assert r["stats"]["ransac_cert_misses"] == 0
+    assert r["log"].replace(out_g, "X") == olog.replace(out_o, "X")
+    _same_files(out_g, out_o)
+    assert r["stats"]["n_keyframes"] == nk and r["stats"]["n_points"] == npnt
+
+
+def test_two_keyframe_pair_ate_two_frames(ctx, tmp_path):
+    """BASELINE config 1: a 2-keyframe 640x480 pair (KLT + RANSAC + triangulate) checked with ate_two_frames
+    (cpp/tools/ate_two_frames.cpp; the build's tool is pinned to the reference tool digit for digit in
+    tests/test_tools.py): the tool's text on the GPU output equals its text on the oracle's output."""
+    seq = synth.make_sequence(2, 640, 480, 2.0, n_blobs=20000, seed=7)
+    cfg = dict(H.PIPE_DEFAULTS, frames=2)
+    outs = {}
+    for tag in ("gpu", "orc"):
+        out = str(tmp_path / tag)
+        if tag == "gpu":
+            r = pipe.run(ctx, seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out)
+            assert r["stats"]["n_keyframes"] == 2
+        else:
+            rc, _, nk, _ = H.orc_pipeline_run(seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out)
+            assert rc == 0 and nk == 2
+        outs[tag] = out
+    _same_files(outs["gpu"], outs["orc"])
+    synth.write_par_ang(str(tmp_path), seq)
+    tool = os.path.join(H.ROOT, H.PKG_NAME, "_build", "ate_two_frames")
+    texts = []
+    for tag in ("gpu", "orc"):
+        for extra in ([], ["--se3"]):
+            p = subprocess.run([tool, "--par", str(tmp_path / "templeRing" / "templeR_par.txt"), "--keyframes",
+                                os.path.join(outs[tag], "keyframes_camera_centers.csv")] + extra, capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr
+            texts.append(p.stdout)
+    assert texts[0] == texts[2] and texts[1] == texts[3]
+    assert "ATE_RMSE:" in texts[0] and "templeR0001.png  ->  [1] templeR0002.png" in texts[0]
+
+
 def test_pipeline_c3_5000_tracks_vs_oracle(ctx, tmp_path):
     """BASELINE config C3 on a prefix the oracle finishes in seconds: 640x480, frame-filling texture,
     klt.max_tracks=5000 / min_tracks=2045 / min_distance=4 -- every output byte vs the oracle, and >= 4500 live tracks

@@ -84,6 +84,25 @@ def test_find_E_ransac(golden):
     assert H.find_E_ransac(O, "orc", golden["tv_K"], golden["tv_pi"][:7], golden["tv_pj"][:7], 10, 1e-3, 1)["ok"] == 0
 
 
+@pytest.mark.parametrize("kind", ["deg_wins", "deg_ties", "clean_wins"])
+def test_find_E_ransac_degenerate_octets(kind):
+    """tests/golden/ransac_degenerate.npz (reference output): repeated-index octets win / tie earlier / tie later."""
+    g = np.load(os.path.join(H.GOLDEN, "ransac_degenerate.npz"))
+    iters, thr, mi = g[f"{kind}_args"]
+    xi, xj, idx8 = g[f"{kind}_xi"], g[f"{kind}_xj"], g[f"{kind}_idx8"]
+    assert np.array_equal(H.uniform_draws(O, "orc", 12345, len(xi), 8 * int(iters)).reshape(-1, 8), idx8)
+    Es = np.array([H.eight_point(O, "orc", xi, xj, d) for d in idx8])
+    H.assert_bits_equal(Es, g[f"{kind}_E"], "E of every iteration (degenerate ones included)")
+    cnt = np.zeros(len(idx8), np.int32)
+    O.call("orc_ransac_counts", None, H.f64(xi), H.f64(xj), len(xi), H.f64(Es), len(idx8), float(thr), cnt)
+    assert np.array_equal(cnt, g[f"{kind}_counts"])
+    r = H.find_E_ransac(O, "orc", g[f"{kind}_K"], g[f"{kind}_pi"], g[f"{kind}_pj"], int(iters), float(thr), int(mi))
+    assert r["ok"] == 1 and r["best_iter"] == int(g[f"{kind}_best"][0])
+    assert np.array_equal(r["inliers"], g[f"{kind}_inl"])
+    H.assert_bits_equal(r["R"], g[f"{kind}_R"], "R")
+    H.assert_bits_equal(r["t"], g[f"{kind}_t"], "t")
+
+
 @pytest.mark.parametrize("n", [3, 4, 9])
 def test_jacobi(golden, n):
     for k, m in enumerate(golden[f"jac_in_{n}"]):
