@@ -50,6 +50,11 @@ def cpu_baseline(seq, cfg, sample_frames: int):
     ref_cli = os.path.join(ROOT, "oracle", "_ref", "templering_sfm_ref")
     sub = {k: (v[:sample_frames] if k in ("images", "R", "t", "names", "lat", "lon") else v) for k, v in seq.items()}
     cores = 1  # the reference is single-threaded
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    host = f"{model}, {os.cpu_count()} logical CPUs visible, 1 used"
     if os.path.exists(ref_cli):
         with tempfile.TemporaryDirectory() as td:
             synth.write_dataset(td, sub)
@@ -58,7 +63,7 @@ def cpu_baseline(seq, cfg, sample_frames: int):
             dt = time.perf_counter() - t0
             if p.returncode == 0:
                 kf = int(p.stdout.split("Keyframes:")[1].split()[0])
-                return dict(value=kf / dt, unit="keyframes/s", cores=cores, kind="reference",
+                return dict(value=kf / dt, unit="keyframes/s", cores=cores, kind="reference", host_cpu=host,
                             sample=f"first {sample_frames} frames of the bench sequence, reference CLI wall time {dt:.2f} s, {kf} keyframes",
                             frames_per_s=sample_frames / dt)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -68,7 +73,7 @@ def cpu_baseline(seq, cfg, sample_frames: int):
         rc, log, nk, npnt = H.orc_pipeline_run(sub["images"], sub["names"], sub["K"], sub["lat"], sub["lon"],
                                                dict(cfg, frames=sample_frames), td)
     dt = time.perf_counter() - t0
-    return dict(value=nk / dt, unit="keyframes/s", cores=cores, kind="port",
+    return dict(value=nk / dt, unit="keyframes/s", cores=cores, kind="port", host_cpu=host,
                 sample=f"first {sample_frames} frames of the bench sequence, oracle restatement wall time {dt:.2f} s, {nk} keyframes",
                 frames_per_s=sample_frames / dt)
 
@@ -203,67 +208,64 @@ def main():
                    "ms_per_step": round(b_dt / b_steps * 1e3, 3), "passes_bit_identical": bool(b_same)}
     if rank == 0:
         st = last["stats"]
-        per_stage = {"klt": prof["us_klt_kernel"], "ransac": prof["us_ransac_kernel"], "ba": prof["us_ba_kernel"], "shi": prof["us_shi_kernel"]}
-        # The roofline object is about ONE kernel: the one with the largest accumulated duration in the committed
-        # rocprofv3 kernel trace of this same command (profiles/r01_bench_kernel_stats.csv).  The BA and RANSAC stage
-        # timers span several kernels per API call (points+expand+reduce+solve; hypotheses+score+argmax), the KLT and
-        # Shi-Tomasi-score timers exactly one, so a stage total is not a kernel total.
-        stage_of = {"k_klt_track": "klt", "k_hypotheses": "ransac", "k_score": "ransac", "k_ba_reduce": "ba", "k_solve_wave": "ba",
-                    "k_ba_points": "ba", "k_shi_score": "shi"}
-        dom = max(per_stage, key=per_stage.get)
-        try:
-            import csv
-            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_bench_kernel_stats.csv"))))
-            top = max((r for r in rows if not r["kernel"].startswith("__amd")), key=lambda r: float(r["total_ms"]))
-            dom = stage_of.get(top["kernel"].replace("void ", "").split("<")[0], dom)
-        except Exception:
-            pass
+        # --- roofline of the DOMINANT kernel of this run: the kernel with the largest accumulated GPU time in the
+        # per-kernel profile of the extra timed pass (HIP events recorded inside libsfmx on each context's own stream
+        # around every launch, summed over the five contexts of the pipeline).  Nothing here is read from a previous
+        # round's files; `traffic` comes from the newest committed PMC summary only if it was taken at this launch size.
+        kern = {k: v for k, v in prof["kernels"].items() if v[1] > 0}
         w, h = 640, 480
-        if dom == "klt":
-            launches = max(1, prof["klt_calls"])
-            avg_us = prof["us_klt_kernel"] / launches
-            tracks = prof["tracks_in"] / launches
-            alg_bytes = 2 * 1.3125 * w * h + 49.0 * tracks            # both pyramids once + track arrays
-            alg_flop = LK_STEP_FLOP * prof["lk_steps"] / launches
-            kname = "k_klt_track"
-        elif dom == "ransac":
-            launches = max(1, prof["ransac_calls"])
-            avg_us = prof["us_ransac_kernel"] / launches
-            npts = prof["ransac_points"] / launches
-            alg_bytes = 32.0 * npts + 76.0 * 2500 + npts               # points + E/count per hypothesis + mask
-            alg_flop = SAMPSON_FLOP * 2500 * npts + 25e3 * 2500
-            kname = "k_hypotheses+k_score"
-        elif dom == "ba":
-            launches = max(1, prof["ba_iters"])
-            avg_us = prof["us_ba_kernel"] / launches
-            alg_bytes = 20.0 * 3600 + 24.0 * 600 + 96 * 6 + 8 * (36 * 36 + 36)
-            alg_flop = 7.2e6
-            kname = "k_ba_points+k_ba_reduce"
-        else:
-            launches = 1
-            avg_us = prof["us_shi_kernel"]
-            alg_bytes = 9.0 * w * h
-            alg_flop = 260.0 * w * h
-            kname = "k_shi_score"
-        ach_gbs = alg_bytes / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-        ach_tf = alg_flop / (avg_us * 1e-6) / 1e12 if avg_us > 0 else 0.0
-        # HBM traffic per launch of that kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
-        # tools/prof_kernels.py at the same sizes; FETCH_SIZE/WRITE_SIZE are KB; byte-granular loads are
-        # uncalibrated on gfx950 -- MI355X_MICROARCH.md §HBM -- so the raw counter sum is reported)
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            for row in pmc:
-                if row["kernel"].replace("void ", "").startswith(kname.split("+")[0]):
-                    traffic = int((row.get("FETCH_SIZE_avg", 0.0) + row.get("WRITE_SIZE_avg", 0.0)) * 1024)
+        n_klt = max(1, prof["klt_calls"])
+        tracks = prof["tracks_in"] / n_klt
+        npts = prof["ransac_points"] / max(1, prof["ransac_calls"])
+        # algorithmic (flop, bytes) per launch -- SURVEY.md 8(d) figures x the units one launch processes
+        alg = {
+            "k_klt_track": (LK_STEP_FLOP * prof["lk_steps"] / n_klt, 2 * 1.3125 * w * h + 49.0 * tracks),
+            "k_hypotheses": (25e3 * 2500, 256.0 * 2500 + 80.0 * 2500),
+            "k_score": (SAMPSON_FLOP * 2500 * npts, 32.0 * npts + 84.0 * 2500),
+            "k_ba_points": (535.0 * 3600, 20.0 * 3600 + 24.0 * 600 + 96 * 6),
+            "k_ba_reduce": (1.0 * 600 * (36 * 36 + 36), 8.0 * 600 * (36 * 36 + 36 + 48)),
+            "k_shi_score": (260.0 * w * h, 9.0 * w * h),
+            "k_downsample2": (4.0 * 0.3125 * w * h, 1.3125 * w * h),
+        }
+        dom = max(kern, key=lambda k: kern[k][0]) if kern else "k_klt_track"
+        dom_us, dom_calls = kern.get(dom, (0.0, 0))
+        avg_us = dom_us / dom_calls if dom_calls else 0.0
+        alg_flop, alg_bytes = alg.get(dom.split(" ")[0], (None, None))
+        ach_tf = alg_flop / (avg_us * 1e-6) / 1e12 if (alg_flop and avg_us > 0) else None
+        ach_gbs = alg_bytes / (avg_us * 1e-6) / 1e9 if (alg_bytes and avg_us > 0) else None
+        traffic, valu_issue = None, None
+        try:  # newest profiles/rNN_pmc_summary.json + its meta (launch sizes of tools/prof_kernels.py)
+            import glob
+            metas = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_meta.json")))
+            if metas:
+                meta = json.load(open(metas[-1]))
+                pmc = json.load(open(metas[-1].replace("_pmc_meta.json", "_pmc_summary.json")))
+                same_size = dom != "k_klt_track" or abs(meta.get("klt_tracks", 0) - tracks) <= 0.1 * tracks
+                for row in pmc:
+                    if row["kernel"].replace("void ", "").startswith(dom.split(" ")[0]) and same_size:
+                        # FETCH_SIZE / WRITE_SIZE are KB; byte-granular loads are uncalibrated on gfx950 (MI355X_MICROARCH.md,
+                        # HBM), so the raw counter sum is what is reported
+                        traffic = int((row.get("FETCH_SIZE_avg", 0.0) + row.get("WRITE_SIZE_avg", 0.0)) * 1024)
+                        if "SQ_INSTS_VALU_avg" in row and dom == "k_klt_track" and meta.get("klt_lk_steps"):
+                            valu_issue = dict(source=os.path.basename(metas[-1]).replace("_pmc_meta.json", "_pmc_summary.json"),
+                                              valu_wave_insts_per_lk_step=round(row["SQ_INSTS_VALU_avg"] / meta["klt_lk_steps"], 1),
+                                              waves=int(row.get("SQ_WAVES_avg", 0)),
+                                              valu_busy_frac=(round(row["SQ_ACTIVE_INST_VALU_avg"] / row["SQ_BUSY_CYCLES_avg"], 4)
+                                                              if "SQ_ACTIVE_INST_VALU_avg" in row and row.get("SQ_BUSY_CYCLES_avg") else None))
         except Exception:
-            traffic = None
-        roofline = dict(bound="hbm", achieved=round(ach_gbs, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gbs / HBM_PEAK_GBS, 6),
-                        traffic=traffic, kernel=kname, avg_launch_us=round(avg_us, 2), launches_per_pass=int(launches),
-                        algorithmic_bytes_per_launch=int(alg_bytes),
-                        note="path is FP64-VALU/latency bound, not HBM bound (SURVEY.md §8d); see fp64_valu",
-                        fp64_valu=dict(achieved=round(ach_tf, 4), peak=FP64_VALU_PEAK_TF, unit="TFLOP/s", frac=round(ach_tf / FP64_VALU_PEAK_TF, 5)),
-                        kernel_us_per_pass={k: round(v, 1) for k, v in per_stage.items()})
+            traffic, valu_issue = None, None
+        roofline = dict(bound="valu_fp64", achieved=None if ach_tf is None else round(ach_tf, 4), peak=FP64_VALU_PEAK_TF, unit="TFLOP/s",
+                        frac=None if ach_tf is None else round(ach_tf / FP64_VALU_PEAK_TF, 5), traffic=traffic,
+                        kernel=dom, avg_launch_us=round(avg_us, 2), launches_per_pass=int(dom_calls),
+                        algorithmic_flop_per_launch=None if alg_flop is None else int(alg_flop),
+                        algorithmic_bytes_per_launch=None if alg_bytes is None else int(alg_bytes),
+                        hbm=dict(achieved=None if ach_gbs is None else round(ach_gbs, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                                 frac=None if ach_gbs is None else round(ach_gbs / HBM_PEAK_GBS, 6)),
+                        valu_issue=valu_issue,
+                        note="ordered FP64 sums make this path VALU-issue / dependent-latency bound, not HBM bound (SURVEY.md 8d): frac is "
+                             "algorithmic FP64 flop/s over the vector FP64 peak, `hbm` the same launch against the HBM roof",
+                        kernel_us_per_pass={k: round(v[0], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
+                        kernel_launches_per_pass={k: v[1] for k, v in kern.items()})
         out = {
             "metric": "keyframes/sec (KLT + RANSAC + local BA per-frame loop), synthetic TempleRing-47 stand-in",
             "value": round(kf_total / dt, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -275,8 +277,8 @@ def main():
                        "parallelism": f"sequences x{world * S}"},
             "frames_per_s": round(args.frames * args.steps * world * S / dt, 2),
             "keyframes_per_step": int(round(kf_total / max(1, args.steps) / world)), "map_points": st["n_points"], "passes_bit_identical": bool(identical),
-            "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_wall", "sec_total", "sec_setup", "sec_klt", "sec_shi", "sec_shi_wait", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_pf_busy", "sec_pf_gpu", "sec_pf_replay", "sec_lane_b_busy", "sec_lane_c_busy", "sec_join_wait", "sec_ba_gather", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_feed_wait")},
-            "counters_per_step": {k: int(st[k]) for k in ("klt_calls", "tracks_in", "lk_steps", "ransac_calls", "ransac_points", "ransac_verified", "ba_calls", "ba_iters", "shi_calls", "shi_memo_hits", "shi_prefetched", "shi_fallbacks")},
+            "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_wall", "sec_total", "sec_setup", "sec_klt", "sec_shi", "sec_shi_wait", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_pf_busy", "sec_pf_gpu", "sec_pf_replay", "sec_lane_a_busy", "sec_lane_b_busy", "sec_lane_c_busy", "sec_join_wait", "sec_ba_gather", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_feed_wait")},
+            "counters_per_step": {k: int(st[k]) for k in ("klt_calls", "tracks_in", "lk_steps", "ransac_calls", "ransac_points", "ransac_verified", "ransac_cert_misses", "ba_calls", "ba_iters", "shi_calls", "shi_memo_hits", "shi_prefetched", "shi_fallbacks")},
             "roofline": roofline,
         }
         # ATE-RMSE of the keyframe centres against the synthetic ground truth, stated by the build's own evaluator

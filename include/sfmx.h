@@ -52,6 +52,11 @@ void* sfmx_stream(sfmx_ctx* ctx);
 int sfmx_set_timing(sfmx_ctx* ctx, int enabled);
 int sfmx_get_timing(const sfmx_ctx* ctx); /* 1 if enabled (so that helper contexts can inherit the setting) */
 double sfmx_last_kernel_us(const sfmx_ctx* ctx);
+/* Per-kernel profile of this context while timing is enabled: accumulated GPU microseconds and launch counts of each
+ * hot kernel (HIP events recorded on the context's stream around every launch).  Enabling timing starts a fresh
+ * profile.  Returns the number of kernel ids; at most cap entries are written; reset != 0 clears after reading. */
+int sfmx_kernel_profile(sfmx_ctx* ctx, int reset, int cap, double* us_out, uint64_t* calls_out);
+const char* sfmx_kernel_profile_name(int id);
 
 /* ---- image pyramid: replaces sfm::GrayImage + build_pyr/downsample2 (T:200-232) ------------ */
 /* level 0 is the image itself; level l is (w>>l) x (h>>l), 2x2 box with integer /4 truncation and
@@ -111,21 +116,22 @@ int sfmx_klt_track(sfmx_ctx* ctx, const sfmx_pyramid* pyr_a, const sfmx_pyramid*
  * Sampson error (T:629-638, bit-exact arithmetic for a given E), counting err < thr.
  *
  * Which E a hypothesis is scored with.  The reference's eight_point_E calls the platform libm
- * (atan2/cos/sin, linalg.hpp:156-157); the device runs the same Jacobi with algebraic rotations,
- * whose result differs from the reference's by rounding only while the smallest eigenvector is
- * well separated.  Where it is not -- octets with a repeated sample index (sampling is with
- * replacement, T:665: null space of dimension >= 2), an eigenvalue / singular-value gap below
- * 1e-5 relative, or a Jacobi pivot nearly tied with another entry -- the library derives the
- * hypothesis on the host with libm (the reference's E bit for bit) and scores that instead
- * (flags bit 0).
+ * (atan2/cos/sin, linalg.hpp:156-157); the device runs the same Jacobi with algebraic rotations and
+ * reports a conditioning estimate cond per hypothesis (relative gap of the two smallest
+ * eigenvalues, relative singular-value gap of the rank-2 projection; 0 if a Jacobi pivot was
+ * nearly tied with another entry).  Its E differs from the reference's by at most 1e-16 / cond per
+ * entry (measured <= 3e-18 / cond).  Octets with a repeated sample index (sampling is with
+ * replacement, T:665: null space of dimension >= 2, cond ~ 0) and hypotheses with cond < 1e-13
+ * are derived on the host with libm instead (the reference's E bit for bit, flags bit 0) and
+ * scored with that.
  *
- * counts_out [H]: #{err < thr}.  lo_out/hi_out [H] (optional): #{err < thr(1-1e-6)} and
- * #{err < thr(1+1e-6)} -- the reference's own count lies in [lo, hi] (the band absorbs the
- * rounding distance between a device hypothesis and the reference's); lo == hi == count for the
- * exact hypotheses.  flags_out [H] (optional): bit 0 = exact host hypothesis.  cond_out [H]
- * (optional): conditioning estimate of the device hypothesis.  best_iter/best_count = argmax of
- * counts with the LOWEST iteration on ties (the reference's strict '>').  E_out [H][9]
- * (optional): the hypotheses that were scored. */
+ * counts_out [H]: #{err < thr}.  lo_out/hi_out [H] (optional): certified bounds of the
+ * REFERENCE's count of that iteration: a point counts for lo only if it stays an inlier, for hi
+ * if it can become one, when every entry of E moves by 1e-16 / cond (per-point bound, see
+ * k_score); lo == hi == count for the exact hypotheses.  flags_out [H] (optional): bit 0 = exact
+ * host hypothesis.  cond_out [H] (optional): the conditioning estimate (+inf for exact ones).
+ * best_iter/best_count = argmax of counts with the LOWEST iteration on ties (the reference's
+ * strict '>').  E_out [H][9] (optional): the hypotheses that were scored. */
 int sfmx_ransac_score_ex(sfmx_ctx* ctx, const double* xi, const double* xj, int n, const int32_t* idx8,
                          int H, double thr, int32_t* counts_out, int32_t* lo_out, int32_t* hi_out,
                          uint8_t* flags_out, double* cond_out, int32_t* best_iter,
@@ -170,6 +176,11 @@ int sfmx_ba_build_partial(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* po
 /* Gaussian elimination with partial pivoting in the reference's operation order; A [n][n]
  * row-major and b [n] are not modified; x [n].  SFMX_ERR_SINGULAR when a pivot is < 1e-15. */
 int sfmx_solve_dense(sfmx_ctx* ctx, const double* A, const double* b, int n, double* x);
+
+/* lk_step evaluations of the last sfmx_klt_track call that could not use the shared sample grid (more distinct
+ * sample coordinates than its descriptor table holds) and took the per-pixel path: a performance counter, the
+ * results are identical either way. */
+uint64_t sfmx_debug_klt_slow_steps(const sfmx_ctx* ctx);
 
 /* ---- self-check hooks used by the parity tests (device arithmetic vs the host libm) ---------- */
 int sfmx_debug_hypot(sfmx_ctx* ctx, const double* x, const double* y, int n, double* out);

@@ -23,11 +23,11 @@ SFMX_OK, SFMX_ERR_INVALID, SFMX_ERR_HIP, SFMX_ERR_NO_DEVICE, SFMX_ERR_SINGULAR, 
 # every symbol include/sfmx.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "sfmx_ctx_create", "sfmx_ctx_create_prio", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_ctx_device", "sfmx_ctx_make_current", "sfmx_stream", "sfmx_set_timing", "sfmx_get_timing",
-    "sfmx_last_kernel_us", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
+    "sfmx_last_kernel_us", "sfmx_kernel_profile", "sfmx_kernel_profile_name", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
     "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_ransac_score_ex", "sfmx_sampson_mask", "sfmx_ba_create",
     "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
-    "sfmx_debug_hypot", "sfmx_debug_divsqrt",
+    "sfmx_debug_hypot", "sfmx_debug_divsqrt", "sfmx_debug_klt_slow_steps",
 ]
 
 
@@ -60,6 +60,8 @@ def load_library() -> ctypes.CDLL:
         _lib.sfmx_last_error.restype = c_char_p
         _lib.sfmx_last_kernel_us.restype = c_double
         _lib.sfmx_stream.restype = c_void_p
+        _lib.sfmx_kernel_profile_name.restype = c_char_p
+        _lib.sfmx_debug_klt_slow_steps.restype = c_uint64
     return _lib
 
 
@@ -181,6 +183,13 @@ class Context:
     def last_kernel_us(self) -> float:
         return float(self.lib.sfmx_last_kernel_us(self.h_))
 
+    def kernel_profile(self, reset: bool = False) -> dict:
+        """{kernel name: (gpu_us, launches)} accumulated on this context since timing was enabled"""
+        us = (c_double * 32)()
+        calls = (c_uint64 * 32)()
+        n = self.lib.sfmx_kernel_profile(self.h_, c_int(1 if reset else 0), c_int(32), us, calls)
+        return {self.lib.sfmx_kernel_profile_name(c_int(i)).decode(): (float(us[i]), int(calls[i])) for i in range(n)}
+
     def sync(self):
         self._chk(self.lib.sfmx_sync(self.h_))
 
@@ -230,6 +239,9 @@ class Context:
         self._chk(self.lib.sfmx_klt_track(self.h_, pa.h_, pb.h_, _p(xy, c_double), c_int(n), byref(cfg), _p(fwd, c_double),
                                           _p(back, c_double), _p(keep, c_uint8), byref(steps)))
         return fwd, back, keep, steps.value
+
+    def klt_slow_steps(self) -> int:
+        return int(self.lib.sfmx_debug_klt_slow_steps(self.h_))
 
     def ransac_score(self, xi, xj, idx8, thr, want_E=False):
         xi, xj = _f64(xi), _f64(xj)

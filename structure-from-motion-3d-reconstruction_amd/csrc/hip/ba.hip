@@ -22,6 +22,8 @@
 // Algorithmic bytes per BA iteration: 20*R + 24*P + 96*W read, 8*(D^2+D) written.
 #include "sfmx_internal.h"
 
+#include <mutex>
+
 #define BA_SLOT 84  // doubles per (point, pose) slot: Hxx 36 | bx 6 | Hxp 18 | G 18 | G*bp 6
 #define BA_MAX_OBS 16
 #define BA_MAX_W 64
@@ -834,7 +836,14 @@ __global__ __launch_bounds__(512) void k_lu_backsub(const double* __restrict__ W
 
 // n == 36 / 60: rows in registers.  n <= 64: wave-synchronous LDS kernel.  Larger systems (pose graphs): blocked
 // elimination over the whole device on a working copy [n][n+1] in ctx->d[7].
+static int launch_solve_kernels(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus);
 static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
+  prof_begin(c, KID_SOLVE);
+  const int rc = launch_solve_kernels(c, dA, db, n, dx, dstatus);
+  prof_end(c);
+  return rc;
+}
+static int launch_solve_kernels(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
   if (n == 36) {  // window of 6 (the reference default) and of 10 (C4): rows in registers
     k_solve_regs<36><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus);
   } else if (n == 60) {
@@ -850,11 +859,16 @@ static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, 
     int* piv = reinterpret_cast<int*>(c->d[7].as<char>() + wbytes + abytes);
     double* scratch = reinterpret_cast<double*>(c->d[7].as<char>() + wbytes + abytes + pbytes);
     constexpr size_t kPanelLds = 156 * 1024;  // 160 KiB of LDS per workgroup minus the kernel's static arrays
-    static bool attr_set = false;
-    if (!attr_set) {
-      SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
-      SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
-      attr_set = true;
+    {  // the dynamic-LDS opt-in is a per-device function attribute; contexts of several host threads may get here at once
+      static std::mutex attr_mu;
+      static bool attr_set[64] = {};
+      std::lock_guard<std::mutex> lk(attr_mu);
+      const int dev = c->device & 63;
+      if (!attr_set[dev]) {
+        SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
+        SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
+        attr_set[dev] = true;
+      }
     }
     k_lu_init<<<256, 256, 0, c->stream>>>(dA, db, n, Wm, dstatus);
     for (int k0 = 0; k0 < n; k0 += LU_NB) {
@@ -882,11 +896,12 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   SFMX_HIP(c, hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
   const int D = 6 * q->W;
   t.start();
-  k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, q->poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy,
-                                                    huber, q->rec, q->slot_of);
+  SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, q->poses, q->X, q->obs_ptr, q->obs_li,
+                                                                                q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of)));
   const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
-  k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib);
-  k_ba_reduce<<<(D * D + D + BAR_COLS - 1) / BAR_COLS, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b);
+  SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
+  SFMX_PROF(c, KID_BA_REDUCE,
+            (k_ba_reduce<<<(D * D + D + BAR_COLS - 1) / BAR_COLS, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b)));
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;

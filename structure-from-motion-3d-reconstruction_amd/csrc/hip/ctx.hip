@@ -51,6 +51,9 @@ void sfmx_ctx_destroy(sfmx_ctx* c) {
   for (auto& b : c->d) b.release();
   for (auto& b : c->wl) b.release();
   for (auto& b : c->h) b.release();
+  for (auto& e : c->pev)
+    for (auto& x : e)
+      if (x) (void)hipEventDestroy(x);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -74,8 +77,28 @@ int sfmx_ctx_make_current(sfmx_ctx* c) {
 void* sfmx_stream(sfmx_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int sfmx_set_timing(sfmx_ctx* c, int enabled) {
   if (!c) return SFMX_ERR_INVALID;
+  if (enabled && !c->timing) {  // a fresh profile for every timed run
+    for (auto& v : c->kus) v = 0.0;
+    for (auto& v : c->kcalls) v = 0;
+  }
   c->timing = enabled != 0;
+  c->prof_n = 0;
   return SFMX_OK;
+}
+int sfmx_kernel_profile(sfmx_ctx* c, int reset, int cap, double* us_out, uint64_t* calls_out) {
+  if (!c) return 0;
+  for (int i = 0; i < KID_COUNT && i < cap; i++) {
+    if (us_out) us_out[i] = c->kus[i];
+    if (calls_out) calls_out[i] = c->kcalls[i];
+    if (reset) { c->kus[i] = 0.0; c->kcalls[i] = 0; }
+  }
+  return KID_COUNT;
+}
+const char* sfmx_kernel_profile_name(int id) {
+  static const char* names[KID_COUNT] = {"k_klt_track", "k_hypotheses", "k_score", "k_ba_points", "k_ba_expand", "k_ba_reduce",
+                                         "solve (k_solve_regs / k_solve_wave / k_lu_*)", "k_shi_score",
+                                         "shi fixpoint (k_shi_round / k_shi_list_* / k_shi_tail)", "k_downsample2"};
+  return (id >= 0 && id < KID_COUNT) ? names[id] : "";
 }
 int sfmx_get_timing(const sfmx_ctx* c) { return (c && c->timing) ? 1 : 0; }
 double sfmx_last_kernel_us(const sfmx_ctx* c) { return c ? c->last_us : 0.0; }

@@ -26,6 +26,8 @@ __global__ void k_downsample2(const uint8_t* __restrict__ src, int sw, int sh, u
 }
 
 static int build_levels(sfmx_ctx* c, sfmx_pyramid* p) {
+  if (p->levels > 1) prof_begin(c, KID_PYRAMID);  // all levels of one image = one profile entry
+  struct End { sfmx_ctx* c; ~End() { prof_end(c); } } end{c};
   for (int l = 1; l < p->levels; l++) {
     if (p->lw[l] <= 0 || p->lh[l] <= 0) continue;
     dim3 b(64, 4), g((p->lw[l] + 63) / 64, (p->lh[l] + 3) / 4);
@@ -501,7 +503,7 @@ static int launch_score(sfmx_ctx* c, const sfmx_pyramid* p, double* d_score, uns
   dim3 b(ST_TX, ST_TY), g((p->w + ST_TX - 1) / ST_TX, (p->h + ST_TY - 1) / ST_TY);
   KernelTimer t(c);
   t.start();
-  k_shi_score<<<g, b, 0, c->stream>>>(p->base + p->off[0], p->w, p->h, d_score, d_max);
+  SFMX_PROF(c, KID_SHI_SCORE, (k_shi_score<<<g, b, 0, c->stream>>>(p->base + p->off[0], p->w, p->h, d_score, d_max)));
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;
@@ -616,6 +618,7 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   int rc = launch_score(c, p, c->d[0].as<double>(), d_max);
   if (rc) return rc;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
+  prof_begin(c, KID_SHI_FIXPOINT);  // init + dense sweeps + work-list sweeps + tail + compaction
   k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag);
   // Sweep 1 over all pixels (LDS tiles), then a fixed number of work-list sweeps.  The fixpoint is normally
   // reached after ~30 sweeps; later sweeps see an empty list and cost ~2 us, and stopping before the
@@ -647,6 +650,7 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   k_row_scan<<<1, 64, 0, c->stream>>>(d_rows_all, p->h, d_tot + 1);
   k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, d_rows_all, cap, d_xy, c->d[4].as<double>(), d_full,
                                           c->d[6].as<double2>());
+  prof_end(c);
   SFMX_HIP(c, hipGetLastError());
   // the 16-byte header plus a speculative download of the first SPEC survivors (there are ~1.5-2 k per
   // VGA frame) through pinned memory; a second trip happens only if there are more

@@ -8,20 +8,29 @@
 //
 //  * LDS staging: a 32x32 window of both pyramid images around the current estimate is copied to
 //    LDS as f32 (u8 -> f32 is exact) once per level and re-staged only when the (2r+5)-wide
-//    footprint of an lk_step leaves it.  Row stride 33 keeps the 11x11 access pattern off the
-//    same bank.
-//  * per-pixel phase (parallel): lane l owns window pixels l, l+64, ...; each pixel evaluates the six
-//    bilinear samples of T:438-441 with the reference's exact expressions (floor, x - x0,
-//    v00*(1-dx)+v10*dx, rows first) and the five products Ix*Ix, Ix*Iy, Iy*Iy, Ix*err, Iy*err.
+//    footprint of an lk_step leaves it.
+//  * sample grid (parallel).  sample_bilinear (T:183-198) is separable in what it needs of a coordinate:
+//    (floor, fraction, in-image test).  An lk_step evaluates I1 at (xx+1,yy), (xx-1,yy), (xx,yy+1), (xx,yy-1),
+//    (xx,yy) and I0 at (xx,yy) for xx = x+dx, yy = y+dy (T:436-441): 6 samples x (2r+1)^2 pixels, but only
+//    ~(2r+3)^2 + (2r+1)^2 DISTINCT ones.  Per step the wave builds one descriptor per distinct coordinate
+//    -- the reference's own expressions fl(x+dx), fl(fl(x+dx)+1), fl(fl(x+dx)-1), matched BITWISE against the
+//    neighbouring fl(x+(dx+-1)) (they differ in the last bit where x+dx crosses a power of two; such values get
+//    descriptor slots of their own, so the grid is exact by construction) -- then each distinct sample once
+//    (rows first: v00*(1-fx)+v10*fx, then v0*(1-fy)+v1*fy, the reference's order), and the pixels read them.
+//    A step with more extra coordinates than the descriptor table holds takes the per-pixel path.
 //  * ordered reduction (serial by contract): FP64 addition is not associative and parity is
 //    bit-exact, so the (2r+1)^2 products of each accumulator are added in the reference's
 //    (dy outer, dx inner) sequence: lanes 0..4 each walk one accumulator's products in LDS.
-//  * 2x2 solve, hypot-based stop test (glibc-compatible hypot, sfmx_math.h), level loop, then the
-//    backward pass from the forward result and keep = !(hypot(back - p0) >= fb_thresh).
+//  * 2x2 solve (the three divisions of T:453-455 in three lanes of one instruction), hypot-based stop test
+//    (glibc-compatible hypot, sfmx_math.h), level loop, then the backward pass from the forward result and
+//    keep = !(hypot(back - p0) >= fb_thresh).
 //
 // No FMA contraction anywhere (-ffp-contract=off); FP64 division and sqrt are the correctly
 // rounded forms.
 #include "sfmx_internal.h"
+
+#include <cstdlib>
+#include <vector>
 
 #define KLT_P 32          // staged window is KLT_P x KLT_P pixels
 // LDS row stride (floats) of the staged windows.  Lane l owns window pixel l = (dy+r)*(2r+1)+(dx+r)
@@ -61,11 +70,34 @@ __device__ __forceinline__ double sample_lds(const float* __restrict__ win, cons
   return v * (cx.m * cy.m);
 }
 
-// Both windows are staged together: all 32 byte loads of a lane are issued before the first LDS
-// store, so one staging costs about one L2 round trip instead of 32 dependent ones.
+// Both windows are staged together: every global load of a lane is issued before the first LDS store, so one staging
+// costs about one L2 round trip.  A window that lies inside the image (the usual case; wave-uniform test) is fetched as
+// 16 bytes per lane and image -- lane = (row, half row), four byte-aligned dword loads -- instead of 16 byte loads.
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 template <int KLT_PS>
 __device__ __forceinline__ void stage_windows(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int w, int h, int ox,
                                               int oy, float* __restrict__ win0, float* __restrict__ win1, int lane) {
+  if (ox >= 0 && oy >= 0 && ox + KLT_P <= w && oy + KLT_P <= h) {
+    static_assert(KLT_P == 32, "two lanes per window row");
+    const int row = lane >> 1, c0 = (lane & 1) * 16;
+    const size_t off = (size_t)(oy + row) * w + ox + c0;
+    const u32_unaligned* a = reinterpret_cast<const u32_unaligned*>(img0 + off);
+    const u32_unaligned* b = reinterpret_cast<const u32_unaligned*>(img1 + off);
+    uint32_t va[4], vb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { va[k] = a[k]; vb[k] = b[k]; }
+    float* d0 = win0 + row * KLT_PS + c0;
+    float* d1 = win1 + row * KLT_PS + c0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        d0[4 * k + q] = (float)((va[k] >> (8 * q)) & 0xffu);
+        d1[4 * k + q] = (float)((vb[k] >> (8 * q)) & 0xffu);
+      }
+    }
+    return;
+  }
   constexpr int N = KLT_P * KLT_P / 64;  // 16 pixels per lane per image
   const int px = lane % KLT_P, py0 = lane / KLT_P;  // lane covers column px of rows py0, py0+2, ...
   const int gx = ox + px;
@@ -111,25 +143,106 @@ __device__ __forceinline__ int book_floor(double v) {
   return (int)floor(v);
 }
 
+// LDS plan of one track (one wavefront) for window radius r
 template <int r>
+struct KltLds {
+  static constexpr int side = 2 * r + 1, npix = side * side, npad = (npix + 1) & ~1;
+  static constexpr int PS = KLT_PS_FOR(r);
+  static constexpr int NCAN = 2 * r + 3;        // grid coordinates per axis: slot 0 = fl(fl(x-r)-1), slot s = fl(x+s-1-r), slot 2r+2 = fl(fl(x+r)+1)
+  static constexpr int GS = NCAN + 1;           // grid row stride (doubles)
+  static constexpr int win_floats = (2 * KLT_P * PS + 3) & ~3;
+  static constexpr size_t o_g1 = (size_t)win_floats * 4;         // double G1[GS][GS]: I1 on the grid
+  static constexpr size_t o_g0 = o_g1 + (size_t)GS * GS * 8;     // double G0[GS][GS]: I0 on the grid
+  static constexpr size_t o_prod = o_g0 + (size_t)GS * GS * 8;   // double prod[5][npad]
+  static constexpr size_t o_tapf = o_prod + (size_t)5 * npad * 8; // double2 {f, 1-f} ({0, 0} outside the image) [2 axes][32]: taps of the grid slots
+  static constexpr size_t o_tapi = o_tapf + (size_t)2 * 32 * 16;  // int byte offset of the tap's column / row inside a window, [2][32]
+  static constexpr size_t o_xtapf = o_tapi + (size_t)2 * 32 * 4;   // double2 taps of off-grid neighbours fl(c_d + 1) / fl(c_d - 1): [2 kinds][2 axes][16]
+  static constexpr size_t o_xtapi = o_xtapf + (size_t)2 * 2 * 16 * 16;  // their byte offsets
+  static constexpr size_t bytes = o_xtapi + (size_t)2 * 2 * 16 * 4;
+  static constexpr int NS = NCAN * NCAN + side * side;           // samples per step: I1 on the grid, I0 on its centre
+  static constexpr int SR = (NS + 63) / 64;                      // sample rounds
+};
+
+template <int CTRL>
+__device__ __forceinline__ long long dpp_i64(long long v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(v & 0xffffffffll), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xF, 0xF, false);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// coordinate of grid slot s on an axis whose step coordinate is v, with the reference's expressions (T:436-439):
+// xx = v + (double)d, xx - 1 for the first slot, xx + 1 for the last one
+template <int r>
+__device__ __forceinline__ double slot_coord(double v, int s) {
+  const int d = min(max(s - 1, 0), 2 * r) - r;
+  const double ca = v + (double)d;
+  return s == 0 ? ca - 1 : (s == 2 * r + 2 ? ca + 1 : ca);
+}
+
+// T:183-198 for one (column tap, row tap) pair on a staged window; omx/omy = 1 - f of the taps
+template <int KLT_PS>
+__device__ __forceinline__ double lerp_lds(const float* __restrict__ win, const Tap& cx, double omx, const Tap& cy, double omy) {
+  const float* p = win + cy.l * KLT_PS + cx.l;
+  const double v00 = (double)p[0], v10 = (double)p[1], v01 = (double)p[KLT_PS], v11 = (double)p[KLT_PS + 1];
+  const double v0 = v00 * omx + v10 * cx.f;
+  const double v1 = v01 * omx + v11 * cx.f;
+  return (v0 * omy + v1 * cy.f) * (cx.m * cy.m);
+}
+
+// STAMP: diagnostic build (SFMX_KLT_STAMPS=1) that accumulates s_memtime deltas per phase of the step loop for track 0
+// into stamps[0..7] (a buffer nothing else reads); the production instantiation has no stamp code.
+template <int r, bool STAMP>
 __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
                                                   int iters, double fb_thresh, double* __restrict__ xy_fwd,
                                                   double* __restrict__ xy_back, uint8_t* __restrict__ keep,
-                                                  unsigned long long* __restrict__ step_counter) {
+                                                  unsigned long long* __restrict__ step_counter, unsigned long long* __restrict__ stamps) {
+  using L = KltLds<r>;
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto stamp = [&](int k) {
+    if (STAMP) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tph[k] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (STAMP) tlast = __builtin_amdgcn_s_memtime();
   extern __shared__ __align__(16) unsigned char smem[];
   float* win0 = reinterpret_cast<float*>(smem);                 // template image window (I0 of lk_step)
   float* win1 = win0 + KLT_P * KLT_PS_FOR(r);                   // current image window  (I1 of lk_step)
-  double* prod = reinterpret_cast<double*>(win0 + ((2 * KLT_P * KLT_PS_FOR(r) + 3) & ~3));  // [5][npix_pad], 16-B aligned
+  double* G1 = reinterpret_cast<double*>(smem + L::o_g1);
+  double* G0 = reinterpret_cast<double*>(smem + L::o_g0);
+  double* prod = reinterpret_cast<double*>(smem + L::o_prod);
+  double2* tapf = reinterpret_cast<double2*>(smem + L::o_tapf);
+  int* tapo = reinterpret_cast<int*>(smem + L::o_tapi);
+  double2* xtapf = reinterpret_cast<double2*>(smem + L::o_xtapf);
+  int* xtapo = reinterpret_cast<int*>(smem + L::o_xtapi);
   const int lane = threadIdx.x;
   const int track = blockIdx.x;
   if (track >= n) return;
-  constexpr int side = 2 * r + 1, npix = side * side;
-  constexpr int npad = (npix + 1) & ~1;
+  constexpr int side = L::side, npix = L::npix, npad = L::npad, NCAN = L::NCAN, GS = L::GS;
   constexpr int KLT_PS = KLT_PS_FOR(r);
-
+  constexpr int PP = (npix + 63) / 64;      // pixels per lane
+  static_assert(NCAN <= 32, "one descriptor lane per grid slot and axis");
+  // the samples of this lane, fixed for the whole kernel.  Sample e < NCAN^2 is I1 at grid point (e / NCAN, e % NCAN), the
+  // others are I0 at the centre points (slots 1..2r+1); a lane without a sample in the last round recomputes sample 0.
+  int samp_cd[L::SR], samp_rd[L::SR];
+  bool samp_i0[L::SR];
+  double* samp_out[L::SR];
+  const bool samp_ok_last = lane + 64 * (L::SR - 1) < L::NS;
+#pragma unroll
+  for (int k = 0; k < L::SR; k++) {
+    int e = lane + 64 * k;
+    if (e >= L::NS) e = 0;
+    samp_i0[k] = e >= NCAN * NCAN;
+    samp_cd[k] = samp_i0[k] ? (e - NCAN * NCAN) % side + 1 : e % NCAN;
+    samp_rd[k] = samp_i0[k] ? (e - NCAN * NCAN) / side + 1 : e / NCAN;
+    samp_out[k] = (samp_i0[k] ? G0 : G1) + samp_rd[k] * GS + samp_cd[k];
+  }
   const double p0x = xy_in[2 * track], p0y = xy_in[2 * track + 1];
   double px = p0x, py = p0y;
-  unsigned int steps = 0;
+  unsigned int steps = 0, slow_steps = 0;
+  // lane roles of the coordinate check: lanes 0..31 the x axis, 32..63 the y axis, lane (axis, dt) owns offset d = dt - r
+  const int dt = lane & 31, daxis = lane >> 5;
 
   for (int dir = 0; dir < 2; ++dir) {
     for (int l = levels - 1; l >= 0; --l) {
@@ -142,13 +255,14 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
       int ox = (int)0x7fffff00, oy = (int)0x7fffff00;  // no window staged yet
       for (int it = 0; it < iters; ++it) {
         const double x = plx + dlx, y = ply + dly;
+        stamp(5);  // level / loop bookkeeping
         // ---- make sure the staged window covers the footprint [b-r-2, b+r+3] of this step
         const int bx = book_floor(x), by = book_floor(y);
         const bool touches = (bx + r + 3 >= 0) && (bx - r - 2 < w) && (by + r + 3 >= 0) && (by - r - 2 < h);
         if (!touches) {
           // Every sample of this step is 0.0 in the reference (T:188) => A = 0, detA = 0 => step {0,0} (T:452)
           // => hypot(0,0) < 1e-3 ends the level (T:416).  Nothing to read: the window may be unstaged, and
-          // stale LDS bits must never reach the mask-multiply in sample_lds (NaN * 0 = NaN).
+          // stale LDS bits must never reach the mask-multiply of a sample (NaN * 0 = NaN).
           ++steps;
           break;
         }
@@ -162,27 +276,129 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
             __syncthreads();
           }
         }
-        // ---- per-pixel products (T:433-449)
-#pragma unroll
-        for (int pix0 = 0; pix0 < npix; pix0 += 64) {
-          const int pix = pix0 + lane;
-          if (pix >= npix) break;
-          const int dyi = pix / side - r, dxi = pix % side - r;
-          const double xx = x + (double)dxi, yy = y + (double)dyi;
-          const Tap cx0 = make_tap(xx, w, ox), cxp = make_tap(xx + 1, w, ox), cxm = make_tap(xx - 1, w, ox);
-          const Tap cy0 = make_tap(yy, h, oy), cyp = make_tap(yy + 1, h, oy), cym = make_tap(yy - 1, h, oy);
-          const double Ix = 0.5 * (sample_lds<KLT_PS>(win1, cxp, cy0) - sample_lds<KLT_PS>(win1, cxm, cy0));
-          const double Iy = 0.5 * (sample_lds<KLT_PS>(win1, cx0, cyp) - sample_lds<KLT_PS>(win1, cx0, cym));
-          const double Iref = sample_lds<KLT_PS>(win0, cx0, cy0);
-          const double Icur = sample_lds<KLT_PS>(win1, cx0, cy0);
-          const double err = Iref - Icur;
-          prod[0 * npad + pix] = Ix * Ix;
-          prod[1 * npad + pix] = Ix * Iy;
-          prod[2 * npad + pix] = Iy * Iy;
-          prod[3 * npad + pix] = Ix * err;
-          prod[4 * npad + pix] = Iy * err;
+        stamp(0);  // window staging
+        // ---- coordinate taps of the grid slots, one lane per slot (lanes 0.. the x axis, 32.. the y axis), and: which of the
+        // reference's neighbour coordinates are ON the grid?  Per axis the reference evaluates c_d = fl(v + d), fl(c_d + 1),
+        // fl(c_d - 1) for d = -r..r (T:436-439).  Slot s = d+r+1 holds c_d, slot 0 holds fl(c_{-r} - 1), slot 2r+2 holds
+        // fl(c_r + 1); fl(c_d + 1) IS slot s+1 iff it equals that slot's coordinate bitwise (it differs in the last bit
+        // where v + d crosses a power of two), likewise fl(c_d - 1) and slot s-1.
+        // mis_p / mis_m: bit d+r (x axis) and 32+d+r (y axis) set = that neighbour needs a sample of its own.
+        unsigned long long mis_p, mis_m;
+        {
+          const double cv = slot_coord<r>(daxis ? y : x, min(dt, NCAN - 1));
+          const long long cbits = __double_as_longlong(cv);
+          // the cross-lane reads run with every lane enabled (a DPP read of a lane that EXEC masks off returns the fill value)
+          long long next_bits, prev_bits;
+          if constexpr (NCAN <= 16) {  // all slots of an axis sit in one DPP row
+            next_bits = dpp_i64<0x101>(cbits);  // row_shl:1 = lane+1
+            prev_bits = dpp_i64<0x111>(cbits);  // row_shr:1 = lane-1
+          } else {
+            next_bits = __shfl_down(cbits, 1, 64);
+            prev_bits = __shfl_up(cbits, 1, 64);
+          }
+          const bool inner = dt >= 1 && dt <= side;  // slots of c_d
+          const bool bad_p = inner & (__double_as_longlong(cv + 1) != next_bits);
+          const bool bad_m = inner & (__double_as_longlong(cv - 1) != prev_bits);
+          mis_p = __ballot(bad_p) >> 1;  // slot s -> bit d+r = s-1
+          mis_m = __ballot(bad_m) >> 1;
+          if (dt < NCAN) {
+            // An out-of-image tap gets BOTH weights 0: every lerp it takes part in is then +0.0, which is what the
+            // reference returns for such a sample (T:188; pixel values are finite and >= 0), with no mask arithmetic.
+            const Tap tp = make_tap(cv, daxis ? h : w, daxis ? oy : ox);
+            const bool ok = tp.m != 0.0;
+            tapf[daxis * 32 + dt] = make_double2(tp.f, ok ? 1 - tp.f : 0.0);
+            tapo[daxis * 32 + dt] = tp.l * (daxis ? KLT_PS * 4 : 4);  // byte offset of the tap's row / column in a window
+          }
+          if (bad_p | bad_m) {  // off-grid neighbours get taps of their own (rare: skipped when no lane needs one)
+            const double ce = bad_p ? cv + 1 : cv - 1;  // a slot with BOTH neighbours off the grid writes the second one below
+            const Tap tp = make_tap(ce, daxis ? h : w, daxis ? oy : ox);
+            const int e = (bad_p ? 0 : 32) + daxis * 16 + (dt - 1);
+            xtapf[e] = make_double2(tp.f, tp.m != 0.0 ? 1 - tp.f : 0.0);
+            xtapo[e] = tp.l * (daxis ? KLT_PS * 4 : 4);
+            if (bad_p & bad_m) {
+              const Tap tq = make_tap(cv - 1, daxis ? h : w, daxis ? oy : ox);
+              xtapf[32 + daxis * 16 + (dt - 1)] = make_double2(tq.f, tq.m != 0.0 ? 1 - tq.f : 0.0);
+              xtapo[32 + daxis * 16 + (dt - 1)] = tq.l * (daxis ? KLT_PS * 4 : 4);
+            }
+          }
         }
         __syncthreads();
+        // ---- I1 on the grid and I0 on its centre: one sample per lane and round (T:183-198, rows first).  All tap reads,
+        // then all pixel reads, then the arithmetic, then the stores: LDS stores between the rounds would order every
+        // later LDS read behind them (one LDS round trip per dependent access instead of three in total).
+        {
+          double2 fx[L::SR], fy[L::SR];
+          int po[L::SR];
+#pragma unroll
+          for (int k = 0; k < L::SR; k++) {
+            fx[k] = tapf[samp_cd[k]];
+            fy[k] = tapf[32 + samp_rd[k]];
+            po[k] = tapo[samp_cd[k]] + tapo[32 + samp_rd[k]];
+          }
+          float pv[L::SR][4];
+#pragma unroll
+          for (int k = 0; k < L::SR; k++) {
+            const float* p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(samp_i0[k] ? win0 : win1) + po[k]);
+            pv[k][0] = p[0]; pv[k][1] = p[1]; pv[k][2] = p[KLT_PS]; pv[k][3] = p[KLT_PS + 1];
+          }
+          double val[L::SR];
+#pragma unroll
+          for (int k = 0; k < L::SR; k++) {
+            const double v0 = (double)pv[k][0] * fx[k].y + (double)pv[k][1] * fx[k].x;
+            const double v1 = (double)pv[k][2] * fx[k].y + (double)pv[k][3] * fx[k].x;
+            val[k] = v0 * fy[k].y + v1 * fy[k].x;
+          }
+#pragma unroll
+          for (int k = 0; k < L::SR; k++)
+            if (k + 1 < L::SR || samp_ok_last) samp_out[k][0] = val[k];  // only the last round has lanes without a sample
+        }
+        __syncthreads();
+        stamp(1);  // coordinate check + grid
+        // ---- per-pixel products (T:440-449) from the grid
+        const bool any_mis = (mis_p | mis_m) != 0ull;  // wave-uniform
+        if (any_mis) ++slow_steps;
+        {
+          double gxp[PP], gxm[PP], gyp[PP], gym[PP], gcc[PP], irf[PP];
+#pragma unroll
+          for (int q = 0; q < PP; q++) {  // all grid reads first (see above)
+            const int pix = lane + 64 * q < npix ? lane + 64 * q : 0;
+            const int i = pix / side, j = pix % side;  // dy = i - r (outer), dx = j - r (inner)
+            const double* gc1 = G1 + (i + 1) * GS + (j + 1);
+            gxp[q] = gc1[1]; gxm[q] = gc1[-1]; gyp[q] = gc1[GS]; gym[q] = gc1[-GS]; gcc[q] = gc1[0];
+            irf[q] = G0[(i + 1) * GS + (j + 1)];
+          }
+          if (any_mis) {  // neighbours that are not grid points: sampled with the taps the tap phase wrote for them
+            auto lerp = [&](const double2& fx, const double2& fy, int off) {
+              const float* p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(win1) + off);
+              const double v0 = (double)p[0] * fx.y + (double)p[1] * fx.x;
+              const double v1 = (double)p[KLT_PS] * fx.y + (double)p[KLT_PS + 1] * fx.x;
+              return v0 * fy.y + v1 * fy.x;
+            };
+#pragma unroll
+            for (int q = 0; q < PP; q++) {
+              const int pix = lane + 64 * q < npix ? lane + 64 * q : 0;
+              const int i = pix / side, j = pix % side;
+              if ((mis_p >> j) & 1ull) gxp[q] = lerp(xtapf[j], tapf[32 + i + 1], xtapo[j] + tapo[32 + i + 1]);
+              if ((mis_m >> j) & 1ull) gxm[q] = lerp(xtapf[32 + j], tapf[32 + i + 1], xtapo[32 + j] + tapo[32 + i + 1]);
+              if ((mis_p >> (32 + i)) & 1ull) gyp[q] = lerp(tapf[j + 1], xtapf[16 + i], tapo[j + 1] + xtapo[16 + i]);
+              if ((mis_m >> (32 + i)) & 1ull) gym[q] = lerp(tapf[j + 1], xtapf[48 + i], tapo[j + 1] + xtapo[48 + i]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < PP; q++) {
+            const int pix = lane + 64 * q;
+            if (pix < npix) {
+              const double Ix = 0.5 * (gxp[q] - gxm[q]), Iy = 0.5 * (gyp[q] - gym[q]), err = irf[q] - gcc[q];
+              prod[0 * npad + pix] = Ix * Ix;
+              prod[1 * npad + pix] = Ix * Iy;
+              prod[2 * npad + pix] = Iy * Iy;
+              prod[3 * npad + pix] = Ix * err;
+              prod[4 * npad + pix] = Iy * err;
+            }
+          }
+        }
+        __syncthreads();
+        stamp(2);  // products
         // ---- ordered sums: lane k < 5 adds accumulator k's products in reference order
         double acc = 0.0;
         if (lane < 5) {
@@ -202,19 +418,23 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
           if (npix & 1) acc += prod[lane * npad + npix - 1];
         }
         __syncthreads();  // products consumed; next iteration may overwrite
+        stamp(3);  // ordered sums
         const double A00 = readlane_f64(acc, 0), A01 = readlane_f64(acc, 1), A11 = readlane_f64(acc, 2);
         const double b0 = readlane_f64(acc, 3), b1 = readlane_f64(acc, 4);
-        // ---- 2x2 solve (T:451-459)
+        // ---- 2x2 solve (T:451-459): inv00 = A11/detA, inv01 = -A01/detA, inv11 = A00/detA in lanes 0, 1, 2 of ONE division
         double sx = 0.0, sy = 0.0;
         const double detA = A00 * A11 - A01 * A01;
         if (!(fabs(detA) < 1e-9)) {
-          const double inv00 = A11 / detA, inv01 = -A01 / detA, inv11 = A00 / detA;
+          const double num = lane == 0 ? A11 : (lane == 1 ? -A01 : A00);
+          const double quo = num / detA;
+          const double inv00 = readlane_f64(quo, 0), inv01 = readlane_f64(quo, 1), inv11 = readlane_f64(quo, 2);
           sx = inv00 * b0 + inv01 * b1;
           sy = inv01 * b0 + inv11 * b1;
         }
         ++steps;
         dlx += sx;
         dly += sy;
+        stamp(4);  // 2x2 solve
         if (hypot_below(sx, sy, 1e-3)) break;
       }
       px = (plx + dlx) * (double)(1 << l);
@@ -232,9 +452,22 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
     }
     const double fb = sfmx::hypot_glibc(px - p0x, py - p0y);
     keep[track] = (fb >= fb_thresh) ? 0 : 1;  // T:362: `if (fb >= thresh) continue;`
-    if (step_counter) atomicAdd(step_counter, (unsigned long long)steps);
+    if (step_counter) {
+      atomicAdd(step_counter, (unsigned long long)steps);
+      if (slow_steps) atomicAdd(step_counter + 1, (unsigned long long)slow_steps);
+    }
+    if (STAMP && stamps) {
+      for (int k = 0; k < 6; k++) stamps[8 * track + k] = tph[k];
+      stamps[8 * track + 6] = steps;
+      stamps[8 * track + 7] = slow_steps;
+    }
   }
 }
+
+template <int r>
+static size_t klt_lds_bytes() { return KltLds<r>::bytes; }
+
+extern "C" uint64_t sfmx_debug_klt_slow_steps(const sfmx_ctx* c) { return c ? c->klt_slow_steps : 0; }
 
 extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_pyramid* pb, const double* xy_in, int n,
                               const sfmx_klt_cfg* cfg, double* xy_fwd, double* xy_back, uint8_t* keep, uint64_t* n_steps_out) {
@@ -258,14 +491,26 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   memcpy(c->h[0].p, xy_in, nb);
   memset(c->h[0].as<char>() + nb, 0, 16);
   SFMX_HIP(c, hipMemcpyAsync(dbase, c->h[0].p, nb + 16, hipMemcpyHostToDevice, c->stream));
-  const int r = cfg->win_radius, npix = (2 * r + 1) * (2 * r + 1), npad = (npix + 1) & ~1;
-  const size_t shmem = (size_t)((2 * KLT_P * KLT_PS_FOR(r) + 3) & ~3) * sizeof(float) + (size_t)5 * npad * sizeof(double);
+  const int r = cfg->win_radius;
   KernelTimer t(c);
   t.start();
-#define KLT_LAUNCH(RR)                                                                                                          \
-  k_klt_track<RR><<<n, 64, shmem, c->stream>>>(make_desc(pa), make_desc(pb), reinterpret_cast<double*>(dbase), n, cfg->levels, cfg->iters, \
-                                               cfg->fb_thresh, reinterpret_cast<double*>(dbase + o_fwd), reinterpret_cast<double*>(dbase + o_back), \
-                                               reinterpret_cast<uint8_t*>(dbase + o_keep), reinterpret_cast<unsigned long long*>(dbase + o_steps))
+  prof_begin(c, KID_KLT);
+  static const bool stamps_on = getenv("SFMX_KLT_STAMPS") != nullptr;  // diagnostic build of the kernel, see k_klt_track
+  unsigned long long* d_stamps = nullptr;
+  if (stamps_on) {
+    SFMX_HIP(c, c->d[1].ensure((size_t)n * 64));
+    d_stamps = c->d[1].as<unsigned long long>();
+    SFMX_HIP(c, hipMemsetAsync(d_stamps, 0, (size_t)n * 64, c->stream));
+  }
+#define KLT_ARGS                                                                                                                          \
+  make_desc(pa), make_desc(pb), reinterpret_cast<double*>(dbase), n, cfg->levels, cfg->iters, cfg->fb_thresh,                             \
+      reinterpret_cast<double*>(dbase + o_fwd), reinterpret_cast<double*>(dbase + o_back), reinterpret_cast<uint8_t*>(dbase + o_keep),  \
+      reinterpret_cast<unsigned long long*>(dbase + o_steps), d_stamps
+#define KLT_LAUNCH(RR)                                                                              \
+  do {                                                                                              \
+    if (stamps_on && RR == 5) k_klt_track<5, true><<<n, 64, klt_lds_bytes<5>(), c->stream>>>(KLT_ARGS); \
+    else k_klt_track<RR, false><<<n, 64, klt_lds_bytes<RR>(), c->stream>>>(KLT_ARGS);               \
+  } while (0)
   switch (r) {
     case 1: KLT_LAUNCH(1); break;
     case 2: KLT_LAUNCH(2); break;
@@ -276,6 +521,8 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
     default: KLT_LAUNCH(7); break;
   }
 #undef KLT_LAUNCH
+#undef KLT_ARGS
+  prof_end(c);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, dbase + o_steps, dev_bytes - nb, hipMemcpyDeviceToHost, c->stream));
@@ -284,9 +531,30 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   const char* hp = c->h[1].as<char>();  // [steps 16][fwd nb][back nb][keep n]
   unsigned long long steps = 0;
   memcpy(&steps, hp, 8);
+  memcpy(&c->klt_slow_steps, hp + 8, 8);
   memcpy(xy_fwd, hp + 16, nb);
   if (xy_back) memcpy(xy_back, hp + 16 + nb, nb);
   memcpy(keep, hp + 16 + 2 * nb, (size_t)n);
   if (n_steps_out) *n_steps_out = steps;
+  if (stamps_on) {  // per-phase s_memtime ticks per lk_step: track 0, the mean over all tracks, and the slowest track
+    std::vector<unsigned long long> st((size_t)n * 8);
+    SFMX_HIP(c, hipMemcpy(st.data(), d_stamps, (size_t)n * 64, hipMemcpyDeviceToHost));
+    auto line = [&](const char* tag, const unsigned long long* v, double div) {
+      const double k = v[6] ? 1.0 / (double)v[6] : 0.0;
+      fprintf(stderr, "klt stamps %-8s (%6.0f steps, %5.0f off-grid): stage %5.0f | check+grid %5.0f | products %5.0f | sums %5.0f | solve %5.0f | loop %5.0f | total ticks %.0f\n",
+              tag, v[6] / div, v[7] / div, v[0] * k, v[1] * k, v[2] * k, v[3] * k, v[4] * k, v[5] * k, (double)(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]) / div);
+    };
+    unsigned long long sum[8] = {}, worst_total = 0;
+    int worst = 0;
+    for (int t = 0; t < n; t++) {
+      unsigned long long tot = 0;
+      for (int k = 0; k < 8; k++) { sum[k] += st[(size_t)8 * t + k]; if (k < 6) tot += st[(size_t)8 * t + k]; }
+      if (tot > worst_total) { worst_total = tot; worst = t; }
+    }
+    line("track 0", &st[0], 1.0);
+    line("mean", sum, (double)n);
+    line("slowest", &st[(size_t)8 * worst], 1.0);
+    fprintf(stderr, "klt stamps slowest track %d at (%.2f, %.2f)\n", worst, xy_in[2 * worst], xy_in[2 * worst + 1]);
+  }
   return SFMX_OK;
 }

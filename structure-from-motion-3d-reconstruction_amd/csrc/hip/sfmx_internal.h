@@ -54,6 +54,14 @@ struct PinBuf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// per-kernel profile (only while ctx->timing): accumulated GPU time and launch count of the hot kernels, measured
+// with HIP events recorded on the context's own stream around each launch
+enum SfmxKid {
+  KID_KLT = 0, KID_HYPOTHESES, KID_SCORE, KID_BA_POINTS, KID_BA_EXPAND, KID_BA_REDUCE, KID_SOLVE, KID_SHI_SCORE, KID_SHI_FIXPOINT,
+  KID_PYRAMID, KID_COUNT
+};
+#define SFMX_PROF_PAIRS 12
+
 struct sfmx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -61,10 +69,17 @@ struct sfmx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   double last_us = 0.0;
+  hipEvent_t pev[SFMX_PROF_PAIRS][2] = {};
+  int prof_kid[SFMX_PROF_PAIRS] = {};
+  int prof_n = 0;
+  bool prof_open = false;
+  double kus[KID_COUNT] = {};
+  unsigned long long kcalls[KID_COUNT] = {};
   std::string err;
   // reusable staging: a few independent device / pinned slabs
   DevBuf d[8];
   PinBuf h[5];
+  unsigned long long klt_slow_steps = 0;  // lk_steps of the last sfmx_klt_track call that took the per-pixel path
   int resident_points = 0;  // #correspondences left in d[0]/d[1] by the last RANSAC call
   int shi_full_count = 0;   // #candidate scores left in d[6] by the last pruned Shi-Tomasi call
   bool shi_keys_in_flight = false;
@@ -113,6 +128,38 @@ extern "C" void sfmx_release_graphs(sfmx_ctx* ctx);  // image.hip: drop the hipG
     if (!(cond)) return sfmx_fail((ctx), SFMX_ERR_INVALID, #cond, hipSuccess);      \
   } while (0)
 
+static inline void prof_begin(sfmx_ctx* c, int kid) {
+  c->prof_open = false;
+  if (!c->timing || c->prof_n >= SFMX_PROF_PAIRS) return;
+  hipEvent_t* e = c->pev[c->prof_n];
+  if (!e[0] && (hipEventCreate(&e[0]) != hipSuccess || hipEventCreate(&e[1]) != hipSuccess)) return;
+  if (hipEventRecord(e[0], c->stream) != hipSuccess) return;
+  c->prof_kid[c->prof_n] = kid;
+  c->prof_open = true;
+}
+static inline void prof_end(sfmx_ctx* c) {
+  if (!c->prof_open) return;
+  c->prof_open = false;
+  if (hipEventRecord(c->pev[c->prof_n][1], c->stream) == hipSuccess) c->prof_n++;
+}
+static inline void prof_collect(sfmx_ctx* c) {  // after the stream has been synchronised
+  for (int i = 0; i < c->prof_n; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->pev[i][0], c->pev[i][1]) == hipSuccess) {
+      c->kus[c->prof_kid[i]] += (double)ms * 1000.0;
+      c->kcalls[c->prof_kid[i]]++;
+    }
+  }
+  c->prof_n = 0;
+}
+// SFMX_PROF(ctx, KID_x, kernel<<<...>>>(...));
+#define SFMX_PROF(ctx, kid, launch) \
+  do {                              \
+    prof_begin((ctx), (kid));       \
+    launch;                         \
+    prof_end((ctx));                \
+  } while (0)
+
 // event timing of the dominant kernel of an API call (only when ctx->timing)
 struct KernelTimer {
   sfmx_ctx* c;
@@ -127,6 +174,7 @@ struct KernelTimer {
     if (c->timing) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_us = (double)ms * 1000.0;
+      prof_collect(c);
     }
   }
 };

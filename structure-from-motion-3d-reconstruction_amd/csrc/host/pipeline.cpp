@@ -404,6 +404,9 @@ double CornerPrefetcher::kernel_us() {
   for (auto& w : workers_) us += w->clock.shi_kernel_us;
   return us;
 }
+void CornerPrefetcher::grab_profile(StageClock& clk) {
+  for (auto& w : workers_) clk.grab_profile(w->ctx);
+}
 std::uint64_t CornerPrefetcher::replays() {
   std::uint64_t n = 0;
   for (auto& w : workers_) n += w->clock.shi_fallbacks;
@@ -982,7 +985,14 @@ float dot_desc(const std::vector<float>& a, const std::vector<float>& b) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ tracker lane
+void StageClock::grab_profile(sfmx_ctx* ctx) {
+  double us[kKernels] = {};
+  std::uint64_t calls[kKernels] = {};
+  const int n = sfmx_kernel_profile(ctx, 1, kKernels, us, calls);
+  for (int i = 0; i < n && i < kKernels; i++) { kernel_us[i] += us[i]; kernel_calls[i] += calls[i]; }
+}
 void StageClock::add(const StageClock& o) {
+  for (int i = 0; i < kKernels; i++) { kernel_us[i] += o.kernel_us[i]; kernel_calls[i] += o.kernel_calls[i]; }
   klt += o.klt; shi += o.shi; ransac += o.ransac; ba += o.ba; upload += o.upload; host += o.host; total += o.total; shi_gpu += o.shi_gpu;
   shi_replay += o.shi_replay; desc += o.desc; bookkeeping += o.bookkeeping;
   r_pre += o.r_pre; r_gpu += o.r_gpu; r_verify += o.r_verify; r_decomp += o.r_decomp; tri_iter += o.tri_iter; tri_solve += o.tri_solve;
@@ -993,12 +1003,15 @@ void StageClock::add(const StageClock& o) {
   shi_calls += o.shi_calls; shi_memo_hits += o.shi_memo_hits; shi_prefetched += o.shi_prefetched;
   shi_wait += o.shi_wait; setup += o.setup;
   pf_busy += o.pf_busy; pf_gpu += o.pf_gpu; pf_replay += o.pf_replay; lane_b_busy += o.lane_b_busy; lane_c_busy += o.lane_c_busy;
+  lane_a_busy += o.lane_a_busy;
   join_wait += o.join_wait; ba_gather += o.ba_gather; m_step += o.m_step; m_ransac += o.m_ransac; m_kf += o.m_kf; feed_wait += o.feed_wait;
 }
 
 FrameFeeder::FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig& cfg, int extra_levels, int desc_level, int n_frames,
-                         bool threaded, CornerPrefetcher* prefetch, int prefetch_depth, StageClock* clk)
-    : src_(src), desc_level_(desc_level), n_frames_(n_frames), prefetch_depth_(prefetch_depth), prefetch_(prefetch), ctx_(caller_ctx), clk_(clk) {
+                         bool threaded, CornerPrefetcher* prefetch, int prefetch_depth, StageClock* clk,
+                         std::function<void(FramePacket&)> on_packet)
+    : src_(src), desc_level_(desc_level), n_frames_(n_frames), prefetch_depth_(prefetch_depth), prefetch_(prefetch),
+      on_packet_(std::move(on_packet)), ctx_(caller_ctx), clk_(clk) {
   if (threaded) {
     pc_ = ContextPool::instance().acquire(sfmx_ctx_device(caller_ctx), prio_env("SFMX_PRIO_TRACKER", 0), ContextPool::TRACKER);
     ctx_ = pc_->ctx;
@@ -1051,6 +1064,7 @@ FramePacket FrameFeeder::produce(int fi) {
   p.corners = tracker_->take_memo(fi);
   clk_->m_step += since(t0);
   const auto td = Clock::now();
+  if (on_packet_) on_packet_(p);  // starts the frame->frame RANSAC on lane A before the descriptor download below
   p.desc = global_desc_32(ctx_, tracker_->current(), desc_level_);
   clk_->desc += since(td);
   return p;
@@ -1127,11 +1141,11 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         !std::getenv("SFMX_NO_CTX_POOL")) {
       warmed_devices.push_back(dev);
       const char* order = std::getenv("SFMX_LANE_ORDER");
-      if (!order) order = "TBPC";
+      if (!order) order = "TBPCA";
       std::vector<PooledCtx*> made;
       for (const char* c = order; *c; ++c) {
         const int role = *c == 'P' ? ContextPool::PREFETCH : *c == 'T' ? ContextPool::TRACKER : *c == 'B' ? ContextPool::LANE_B
-                         : *c == 'C' ? ContextPool::LANE_C : 0;
+                         : *c == 'C' ? ContextPool::LANE_C : *c == 'A' ? ContextPool::LANE_A : 0;
         if (role) made.push_back(ContextPool::instance().acquire(dev, 0, role));
       }
       for (PooledCtx* pc : made) ContextPool::instance().release(pc);
@@ -1146,7 +1160,33 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   // Tracker lane (FrameFeeder): SFMX_NO_ASYNC / SFMX_NO_TRACK_LANE run KLTTracker::step inline on the caller's context.
   const int n_frames = std::min(cfg.frames, src.count());
   const bool track_lane = !std::getenv("SFMX_NO_ASYNC") && !std::getenv("SFMX_NO_TRACK_LANE") && n_frames > 1;
-  FrameFeeder feeder(ctx, src, cfg.klt, dlevel + 1, dlevel, n_frames, track_lane, prefetch.get(), prefetch_workers + 1, &clk);
+  // Lane A: the frame->frame find_E_ransac (T:1739) is a pure function of the tracker's StepOut (RNG seeded inside, T:657), so
+  // it starts as soon as the tracker lane has produced the packet, on a context of its own; the geometry lane picks the result
+  // up with the packet (SFMX_NO_RANSAC_LANE=1: computed by the geometry lane itself, as before).
+  StageClock lane_a_clk;
+  std::unique_ptr<AsyncLane> lane_a;
+  if (track_lane && !std::getenv("SFMX_NO_RANSAC_LANE"))
+    lane_a = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A);
+  if (lane_a && sfmx_get_timing(ctx)) (void)sfmx_set_timing(lane_a->ctx(), 1);
+  std::function<void(FramePacket&)> on_packet;
+  if (lane_a)
+    on_packet = [&lane_a, &lane_a_clk, K](FramePacket& p) {
+      if (p.step.prev_pts.empty()) return;
+      auto prom = std::make_shared<std::promise<std::optional<RelPose>>>();
+      p.rel = prom->get_future().share();
+      auto pi = std::make_shared<const std::vector<V2>>(p.step.prev_pts);
+      auto pj = std::make_shared<const std::vector<V2>>(p.step.cur_pts);
+      AsyncLane* la = lane_a.get();
+      StageClock* ck = &lane_a_clk;
+      la->submit([prom, pi, pj, la, ck, K]() {
+        try {
+          prom->set_value(find_E_ransac_gpu(la->ctx(), K, *pi, *pj, 2500, 1e-3, 60, ck));
+        } catch (...) {
+          prom->set_exception(std::current_exception());
+        }
+      });
+    };
+  FrameFeeder feeder(ctx, src, cfg.klt, dlevel + 1, dlevel, n_frames, track_lane, prefetch.get(), prefetch_workers + 1, &clk, on_packet);
   CornerDetector geo_det(ctx, &clk);                                  // loop closure: corners of old keyframe images ...
   std::unordered_map<int, std::shared_ptr<const CornerMemo>> kf_corners;  // ... unless their sequence is already known
   // only the first `loop_corners` corners of a keyframe image are ever asked for again (T:1838-1841): keep that prefix
@@ -1283,7 +1323,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     const std::vector<V2>& p_i = step.prev_pts;
     const std::vector<V2>& p_j = step.cur_pts;
     const auto tm1 = Clock::now();
-    auto rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk);  // T:1739
+    std::optional<RelPose> rel;
+    if (pkt.rel.valid()) rel = pkt.rel.get();                                     // T:1739, started ahead on lane A
+    else rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk);
     clk.m_ransac += since(tm1);
     int inliers = 0;
     double parallax = 0.0;
@@ -1456,6 +1498,22 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   }
   join_lane();
   feeder.finish();
+  if (lane_a) {
+    lane_a->wait();
+    clk.lane_a_busy = lane_a->busy_seconds();
+    clk.ransac += lane_a_clk.ransac; clk.ransac_kernel_us += lane_a_clk.ransac_kernel_us; clk.ransac_calls += lane_a_clk.ransac_calls;
+    clk.ransac_points += lane_a_clk.ransac_points; clk.ransac_verified += lane_a_clk.ransac_verified;
+    clk.ransac_cert_misses += lane_a_clk.ransac_cert_misses;
+    clk.r_pre += lane_a_clk.r_pre; clk.r_gpu += lane_a_clk.r_gpu; clk.r_verify += lane_a_clk.r_verify; clk.r_decomp += lane_a_clk.r_decomp;
+    if (sfmx_get_timing(ctx)) clk.grab_profile(lane_a->ctx());
+  }
+  if (sfmx_get_timing(ctx)) {  // per-kernel profiles of every context that worked on this run
+    clk.grab_profile(ctx);
+    if (feeder.threaded()) clk.grab_profile(feeder.ctx());
+    if (lane) clk.grab_profile(lane->ctx());
+    if (lane_c) clk.grab_profile(lane_c->ctx());
+    if (prefetch) prefetch->grab_profile(clk);
+  }
   if (feeder.threaded()) clk.add(feeder.lane_clock());
   if (lane) clk.lane_b_busy = lane->busy_seconds();
   if (lane_c) clk.lane_c_busy = lane_c->busy_seconds();
@@ -1549,6 +1607,9 @@ struct sfmx_pipeline_stats {
   double sec_pf_busy, sec_pf_gpu, sec_pf_replay, sec_lane_b_busy, sec_lane_c_busy, sec_join_wait, sec_ba_gather;
   double sec_m_step, sec_m_ransac, sec_m_kf, sec_feed_wait;
   unsigned long long ransac_cert_misses;
+  double us_kernel[16];
+  unsigned long long calls_kernel[16];
+  double sec_lane_a_busy;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -1595,7 +1656,9 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
                                    c.klt_kernel_us, c.ransac_kernel_us, c.ba_kernel_us, c.shi_kernel_us,
                                    c.lk_steps, c.tracks_in, c.klt_calls, c.ransac_calls, c.ransac_points, c.ba_calls, c.ba_iters, c.ransac_verified, c.shi_fallbacks, c.shi_calls, c.shi_memo_hits, c.shi_prefetched, c.shi_wait, c.setup, wall,
                                    c.pf_busy, c.pf_gpu, c.pf_replay, c.lane_b_busy, c.lane_c_busy, c.join_wait, c.ba_gather,
-                                   c.m_step, c.m_ransac, c.m_kf, c.feed_wait, c.ransac_cert_misses};
+                                   c.m_step, c.m_ransac, c.m_kf, c.feed_wait, c.ransac_cert_misses, {}, {}};
+      for (int i = 0; i < 16; i++) { stats->us_kernel[i] = c.kernel_us[i]; stats->calls_kernel[i] = c.kernel_calls[i]; }
+      stats->sec_lane_a_busy = c.lane_a_busy;
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {

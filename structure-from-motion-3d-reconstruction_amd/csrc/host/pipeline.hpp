@@ -9,6 +9,7 @@
 #include <deque>
 #include <exception>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -73,9 +74,14 @@ struct StageClock {
   std::uint64_t ransac_cert_misses = 0;  // a certified inlier count that did not hold (parity fallback taken)
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
   double shi_wait = 0, setup = 0;
-  double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_b_busy = 0, lane_c_busy = 0, join_wait = 0, ba_gather = 0;
+  double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_a_busy = 0, lane_b_busy = 0, lane_c_busy = 0, join_wait = 0, ba_gather = 0;
   double m_step = 0, m_ransac = 0, m_kf = 0;  // wall time of tracker.step (tracker lane) / frame->frame RANSAC / keyframe block
   double feed_wait = 0;                        // geometry lane waiting for the tracker lane
+  // per-kernel GPU time / launches over every context of the run (sfmx_kernel_profile; only with timing enabled)
+  static constexpr int kKernels = 16;
+  double kernel_us[kKernels] = {};
+  std::uint64_t kernel_calls[kKernels] = {};
+  void grab_profile(sfmx_ctx* ctx);            // adds (and clears) the context's profile
   void add(const StageClock& o);               // field-wise sum (lane clocks are folded into the run's clock)
 };
 
@@ -101,7 +107,7 @@ struct PooledCtx {
 class ContextPool {
  public:
   static ContextPool& instance();
-  enum Role { PREFETCH = 1, TRACKER = 2, LANE_B = 3, LANE_C = 4 };
+  enum Role { PREFETCH = 1, TRACKER = 2, LANE_B = 3, LANE_C = 4, LANE_A = 5 };
   PooledCtx* acquire(int device, int priority, int role);
   void release(PooledCtx* pc);  // synchronises the context; the caller's threads must have stopped using it
   void clear();
@@ -156,6 +162,7 @@ class CornerPrefetcher {
   void discard_older_than(int frame);               // drop finished results of frames < frame that nobody took
   bool matches(double quality, int min_dist) const { return quality == quality_ && min_dist == min_dist_; }
   double kernel_us();                               // accumulated device time of the workers' score kernels
+  void grab_profile(StageClock& clk);               // per-kernel profiles of the workers' contexts (call after the run)
   void busy(double& total, double& gpu, double& replay);  // seconds over all workers (call after the run)
   std::uint64_t replays();                          // tie-order replays over all workers (call after the run)
 
@@ -249,6 +256,13 @@ class GpuTracker {
   std::unordered_map<int, CornerMemo> corner_cache_;
 };
 
+struct RelPose {
+  Mat3 R_ji;
+  V3 t_ji;
+  std::vector<int> inliers;
+  int best_iter = -1;
+};
+
 // What the geometry lane needs of one frame.  pyr stays valid until FrameFeeder::release_upto(fi).
 struct FramePacket {
   int fi = -1;
@@ -257,6 +271,9 @@ struct FramePacket {
   const sfmx_pyramid* pyr = nullptr;             // this frame's pyramid (tracker context, same device)
   std::vector<float> desc;                       // global_desc_32 of the frame (T:1100-1122)
   std::shared_ptr<const CornerMemo> corners;     // accepted-corner sequence, if this frame's image was detected
+  // frame->frame find_E_ransac of this step (T:1739), when it was started ahead of the geometry lane (lane A): a pure
+  // function of step.prev_pts / cur_pts (RNG seeded inside, T:657).  get() rethrows what it threw ("Singular K").
+  std::shared_future<std::optional<RelPose>> rel;
 };
 
 // Tracker lane.  KLTTracker::step depends on the images and on its own previous state only -- never on poses, keyframe
@@ -265,8 +282,9 @@ struct FramePacket {
 // ahead; inline mode (threaded = false) produces each packet inside next() on the caller's context.
 class FrameFeeder {
  public:
+  // on_packet (optional) runs on the producing thread right after a packet is complete, before it is queued
   FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig& cfg, int extra_levels, int desc_level, int n_frames, bool threaded,
-              CornerPrefetcher* prefetch, int prefetch_depth, StageClock* clk);
+              CornerPrefetcher* prefetch, int prefetch_depth, StageClock* clk, std::function<void(FramePacket&)> on_packet = nullptr);
   ~FrameFeeder();
   FrameFeeder(const FrameFeeder&) = delete;
   FrameFeeder& operator=(const FrameFeeder&) = delete;
@@ -275,6 +293,7 @@ class FrameFeeder {
   void finish();                  // waits for the lane to end (all packets produced); its clock may be read afterwards
   int levels_total() const { return tracker_->levels_total(); }
   bool threaded() const { return pc_ != nullptr; }
+  sfmx_ctx* ctx() const { return ctx_; }
   StageClock& lane_clock() { return lane_clk_; }  // the tracker lane's own counters (threaded mode; read after the run)
 
  private:
@@ -283,6 +302,7 @@ class FrameFeeder {
   FrameSource& src_;
   int desc_level_, n_frames_, next_frame_ = 0, ring_ = 2, prefetch_depth_;
   CornerPrefetcher* prefetch_;
+  std::function<void(FramePacket&)> on_packet_;
   PooledCtx* pc_ = nullptr;
   sfmx_ctx* ctx_;
   StageClock lane_clk_;
@@ -301,12 +321,6 @@ class FrameFeeder {
 void klt_pairs(sfmx_ctx* ctx, const LKConfig& cfg, const sfmx_pyramid* a, const sfmx_pyramid* b, const std::vector<V2>& p0, std::vector<V2>& fwd,
                std::vector<std::uint8_t>& keep, StageClock* clk);
 
-struct RelPose {
-  Mat3 R_ji;
-  V3 t_ji;
-  std::vector<int> inliers;
-  int best_iter = -1;
-};
 // find_E_ransac (T:646-761); throws std::runtime_error("Singular K") like the reference
 std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
                                          double thr, int min_inliers, StageClock* clk);

@@ -19,7 +19,7 @@ class WorkerTeam {
   WorkerTeam() {
     int want = 0;
     if (const char* e = std::getenv("SFMX_HOST_THREADS")) want = std::atoi(e);
-    if (want <= 0) want = std::min(8, std::max(1, (int)std::thread::hardware_concurrency() / 2));
+    if (want <= 0) want = std::min(16, std::max(1, (int)std::thread::hardware_concurrency() / 2));
     for (int i = 1; i < want; i++) workers_.emplace_back([this] { worker(); });
   }
   ~WorkerTeam() {

@@ -37,10 +37,16 @@ class PipelineStats(ctypes.Structure):
                 ("sec_setup", c_double), ("sec_wall", c_double), ("sec_pf_busy", c_double), ("sec_pf_gpu", c_double),
                 ("sec_pf_replay", c_double), ("sec_lane_b_busy", c_double), ("sec_lane_c_busy", c_double),
                 ("sec_join_wait", c_double), ("sec_ba_gather", c_double), ("sec_m_step", c_double), ("sec_m_ransac", c_double),
-                ("sec_m_kf", c_double), ("sec_feed_wait", c_double), ("ransac_cert_misses", c_ulonglong)]
+                ("sec_m_kf", c_double), ("sec_feed_wait", c_double), ("ransac_cert_misses", c_ulonglong),
+                ("us_kernel", c_double * 16), ("calls_kernel", c_ulonglong * 16), ("sec_lane_a_busy", c_double)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("us_kernel", "calls_kernel")}
+        lib = capi.load_library()
+        # per-kernel GPU time (us) and launches over every context of the run; filled only when timing was enabled
+        d["kernels"] = {lib.sfmx_kernel_profile_name(c_int(i)).decode(): (float(self.us_kernel[i]), int(self.calls_kernel[i]))
+                        for i in range(16) if lib.sfmx_kernel_profile_name(c_int(i))}
+        return d
 
 
 DEFAULTS = dict(frames=12, export_pointcloud=1, max_tracks=2200, min_tracks=900, quality=0.01, min_distance=8,

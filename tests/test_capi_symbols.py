@@ -11,7 +11,7 @@ def test_libsfmx_exports_header_symbols():
     assert os.path.exists(capi.LIB_PATH), "libsfmx.so not built: python -c 'import __graft_entry__ as g; g.build()'"
     lib = ctypes.CDLL(capi.LIB_PATH)
     hdr = open(os.path.join(H.ROOT, "include", "sfmx.h")).read()
-    declared = set(re.findall(r"^(?:int|void|void\*|double|const char\*)\s+(sfmx_[a-z0-9_]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|void|void\*|double|uint64_t|const char\*)\s+(sfmx_[a-z0-9_]+)\s*\(", hdr, re.M))
     assert declared, "no declarations parsed"
     assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
     for s in sorted(declared):

@@ -22,7 +22,7 @@ pts = I.corners(ctx, pa, 2200)
 for T in (len(pts), 500, 64):
     r = med(lambda: ctx.klt_track(pa, pb, pts[:T]))
     fwd, back, keep, steps = ctx.klt_track(pa, pb, pts[:T])
-    print(f"klt T={T}: med/min us {r}, lk_steps {steps}, kept {int(keep.sum())}")
+    print(f"klt T={T}: med/min us {r}, lk_steps {steps}, per-pixel-path steps {ctx.klt_slow_steps()}, kept {int(keep.sum())}")
 print("shi score:", med(lambda: ctx.shi_score(pa)))
 print("shi cand pruned:", med(lambda: ctx.shi_candidates_pruned(pa, 0.01, 8)), "n,ntot=", ctx.shi_candidates_pruned(pa, 0.01, 8)[4:6])
 for N in (240, 1500, 5000):

@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """Fixed small workload for rocprofv3 PMC passes: the hot kernels at bench-like sizes.
 Usage (GPU box):  rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/prof_kernels.py"""
-import os, sys
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _inputs as I
+# launch size of the KLT kernel: the bench workload tracks ~1240 points per call on average (BENCH line: tracks_in / klt_calls)
+TRACKS = int(os.environ.get("SFMX_PROF_TRACKS", "1240"))
 ctx = I.capi.Context(0)
 seq = I.synth.make_sequence(2, 640, 480, 0.3, n_blobs=20000, seed=7)
 a, b = seq["images"]
 pa, pb = ctx.pyramid(a, 3), ctx.pyramid(b, 3)
-pts = I.corners(ctx, pa, 2200)
+pts = I.corners(ctx, pa, 2200)[:TRACKS]
 for _ in range(5):
     fwd, back, keep, steps = ctx.klt_track(pa, pb, pts)
 print("klt tracks", len(pts), "lk_steps", steps)
+meta = {"klt_tracks": len(pts), "klt_lk_steps": int(steps), "ransac_points": 1100, "ransac_hypotheses": 2500, "ba_W": 6, "ba_P": 600}
+if os.environ.get("SFMX_PROF_META"):
+    json.dump(meta, open(os.environ["SFMX_PROF_META"], "w"))
 N = 1100
 xi, xj = I.two_view(N)
 idx8 = I.octets(N, 2500)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): every measurement the round's profiles/ directory holds.
+#   tools/profile_round.sh r02
+# rocprofv3 passes follow MI355X_MICROARCH.md: counters in their own runs (one group per pass), never combined with
+# --sys-trace / runtime traces; the program itself after `--` (python3, no env/bash hop).
+set -e -o pipefail
+TAG=${1:-rXX}
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT" profiles
+export TMPDIR=/tmp
+python bench.py > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+cp "$OUT/bench_line.json" "profiles/${TAG}_bench_line.json"
+echo "bench line done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --batched-probe 0 > "$OUT/bench_trace.log" 2>&1
+echo "bench trace done"
+export SFMX_PROF_META="$PWD/profiles/${TAG}_pmc_meta.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pmc/trace" -- python3 tools/prof_kernels.py > "$OUT/pmc_trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc/fetch" -- python3 tools/prof_kernels.py > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc/write" -- python3 tools/prof_kernels.py > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc/sq" -- python3 tools/prof_kernels.py > "$OUT/pmc_sq.log" 2>&1
+echo "pmc passes done"
+python tools/summarize_profiles.py "$TAG" "$OUT/bench_trace" "$OUT/pmc"
+python tools/microbench.py > "profiles/${TAG}_microbench.txt" 2>&1
+mkdir -p "gpurun_out/profiles_$TAG" && cp profiles/${TAG}_* "gpurun_out/profiles_$TAG/"
+echo "profiles written: $(ls profiles | grep "^$TAG" | tr '\n' ' ')"
