@@ -394,4 +394,38 @@ int ref_sparse_mesh(const double* K9, const double* pose12, const double* X, int
   return (int)v.size();
 }
 
+// cpp/include/pgm_io.hpp:36-54: 0 = ok (size and byte sum of the pixels), 1 = it threw (message in err)
+int ref_read_pgm(const char* path, int* w, int* h, unsigned long long* checksum, char* err, int cap) {
+  try {
+    const sfm::GrayImage im = sfm::read_pgm(path);
+    *w = im.w;
+    *h = im.h;
+    unsigned long long s = 0;
+    for (size_t i = 0; i < im.pix.size(); i++) s += (unsigned long long)im.pix[i] * (i % 251 + 1);
+    *checksum = s;
+    return 0;
+  } catch (const std::exception& e) {
+    std::snprintf(err, (size_t)cap, "%s", e.what());
+    return 1;
+  }
+}
+
+// minijson::parse + jpick({"cpp",sec,key},{"common",sec,key}) + jint / jdouble / jstring (T:65-106).
+// kind 0 = int, 1 = double, 2 = string.  1 = found, 0 = absent or of another type, -1 = the parser threw (message in text_out)
+int ref_config_lookup(const char* json, const char* section, const char* key, int kind, double* num_out, char* text_out, int cap) {
+  try {
+    const minijson::Value root = minijson::parse(json);
+    const minijson::Value* v = jpick(root, {"cpp", section, key}, {"common", section, key});
+    if (kind == 0) { const auto r = jint(v); if (!r) return 0; *num_out = *r; return 1; }
+    if (kind == 1) { const auto r = jdouble(v); if (!r) return 0; *num_out = *r; return 1; }
+    const auto r = jstring(v);
+    if (!r) return 0;
+    std::snprintf(text_out, (size_t)cap, "%s", r->c_str());
+    return 1;
+  } catch (const std::exception& e) {
+    std::snprintf(text_out, (size_t)cap, "%s", e.what());
+    return -1;
+  }
+}
+
 }  // extern "C"

@@ -5,6 +5,8 @@
 #include <cctype>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <iterator>
 #include <fstream>
 #include <map>
 #include <memory>
@@ -20,193 +22,220 @@
 namespace sfmx_cli {
 
 // ------------------------------------------------------------------------------------------ JSON
-struct Json {
-  enum class T { Null, Bool, Num, Str, Obj, Arr } type = T::Null;
-  bool b = false;
-  double num = 0.0;
-  std::string str;
-  std::vector<std::pair<std::string, Json>> obj;  // first occurrence of a key wins (emplace semantics)
-  std::vector<Json> arr;
-  const Json* get(const std::string& k) const {
-    if (type != T::Obj) return nullptr;
-    for (const auto& kv : obj)
-      if (kv.first == k) return &kv.second;
-    return nullptr;
-  }
-};
-
-class JsonParser {
+// config.json reader (the reference reads it with cpp/include/minijson.hpp; behaviour kept: first occurrence of a
+// duplicate key wins, numbers go through strtod, \uXXXX becomes UTF-8 without surrogate pairing, and the error texts,
+// which reach the user behind "Failed to parse config.json: <path> | ").  Structure: a single-pass scanner that
+// fills a flat node table -- containers are kept on an explicit stack, nothing recurses.
+class Json {
  public:
-  explicit JsonParser(const std::string& s) : p_(s.c_str()), end_(s.c_str() + s.size()) {}
-  Json parse() {
-    ws();
-    Json v = value();
-    ws();
-    if (p_ != end_) throw std::runtime_error("Trailing characters after JSON");
-    return v;
+  enum class Kind : std::uint8_t { Null, Bool, Number, String, Object, Array };
+  struct Node {
+    Kind kind = Kind::Null;
+    bool flag = false;
+    double number = 0.0;
+    std::string text;             // String: the value
+    std::string key;              // member name when the parent is an Object
+    int parent = -1, next = -1;   // next sibling in source order
+    int first = -1, last = -1;    // children of Object / Array
+  };
+  // view of one value inside a parsed document
+  struct Ref {
+    const Json* doc = nullptr;
+    int id = -1;
+    explicit operator bool() const { return doc != nullptr && id >= 0; }
+    const Node& node() const { return doc->nodes_[(size_t)id]; }
+    Ref member(const char* name) const {  // first member with that name (later duplicates were never stored)
+      if (!*this || node().kind != Kind::Object) return {};
+      for (int c = node().first; c >= 0; c = doc->nodes_[(size_t)c].next)
+        if (doc->nodes_[(size_t)c].key == name) return {doc, c};
+      return {};
+    }
+  };
+  Ref root() const { return {this, nodes_.empty() ? -1 : 0}; }
+
+  static Json parse(const std::string& text) {
+    Json doc;
+    Scanner sc{text.data(), text.data() + text.size()};
+    std::vector<int> open;  // containers being filled, innermost last
+    std::string pending_key;
+    bool have_key = false;
+    // state: what may come next inside the innermost container
+    enum class Expect { Value, FirstMemberOrEnd, Member, FirstElementOrEnd, CommaOrEnd } expect = Expect::Value;
+    auto attach = [&](Node&& n) -> int {
+      const int id = (int)doc.nodes_.size();
+      bool keep = true;
+      if (!open.empty()) {
+        n.parent = open.back();
+        Node& par = doc.nodes_[(size_t)n.parent];
+        if (par.kind == Kind::Object) {
+          n.key = std::move(pending_key);
+          for (int c = par.first; c >= 0; c = doc.nodes_[(size_t)c].next)
+            if (doc.nodes_[(size_t)c].key == n.key) keep = false;  // duplicate key: the first one stays
+        }
+      }
+      doc.nodes_.push_back(std::move(n));
+      if (keep && !open.empty()) {
+        Node& par = doc.nodes_[(size_t)open.back()];
+        if (par.last >= 0) doc.nodes_[(size_t)par.last].next = id;
+        else par.first = id;
+        par.last = id;
+      }
+      have_key = false;
+      return id;
+    };
+    for (;;) {
+      sc.skip_space();
+      if (expect == Expect::Value || expect == Expect::FirstElementOrEnd) {
+        if (expect == Expect::FirstElementOrEnd && sc.take(']')) {
+          open.pop_back();
+        } else {
+          if (sc.at_end()) sc.fail("Unexpected end of input");
+          const char c = sc.peek();
+          Node n;
+          if (c == '{' || c == '[') {
+            sc.take(c);
+            n.kind = c == '{' ? Kind::Object : Kind::Array;
+            open.push_back(attach(std::move(n)));
+            expect = c == '{' ? Expect::FirstMemberOrEnd : Expect::FirstElementOrEnd;
+            continue;
+          }
+          if (c == '"') { n.kind = Kind::String; n.text = sc.quoted(); }
+          else if (c == 'n') { if (!sc.literal("null")) sc.fail("Invalid token (expected null)"); }
+          else if (c == 't' || c == 'f') {
+            n.kind = Kind::Bool;
+            if (sc.literal("true")) n.flag = true;
+            else if (!sc.literal("false")) sc.fail("Invalid token (expected true/false)");
+          }
+          else if (c == '-' || (c >= '0' && c <= '9')) { n.kind = Kind::Number; n.number = sc.number(); }
+          else sc.fail(std::string("Unexpected character '") + c + "'");
+          attach(std::move(n));
+        }
+      } else if (expect == Expect::FirstMemberOrEnd || expect == Expect::Member) {
+        if (expect == Expect::FirstMemberOrEnd && sc.take('}')) {
+          open.pop_back();
+        } else {
+          if (sc.at_end() || sc.peek() != '"') sc.fail("Expected string key");
+          pending_key = sc.quoted();
+          have_key = true;
+          sc.skip_space();
+          if (!sc.take(':')) sc.fail("Expected ':'");
+          expect = Expect::Value;
+          continue;
+        }
+      } else {  // CommaOrEnd
+        const bool in_object = doc.nodes_[(size_t)open.back()].kind == Kind::Object;
+        if (sc.take(in_object ? '}' : ']')) {
+          open.pop_back();
+        } else {
+          if (!sc.take(',')) sc.fail("Expected ','");
+          expect = in_object ? Expect::Member : Expect::Value;
+          continue;
+        }
+      }
+      // a complete value has just ended
+      if (open.empty()) break;
+      expect = Expect::CommaOrEnd;
+    }
+    (void)have_key;
+    sc.skip_space();
+    if (!sc.at_end()) throw std::runtime_error("Trailing characters after JSON");
+    return doc;
   }
 
  private:
-  const char* p_;
-  const char* end_;
-  [[noreturn]] void err(const std::string& m) { throw std::runtime_error("JSON parse error: " + m); }
-  void ws() { while (p_ < end_ && std::isspace((unsigned char)*p_)) ++p_; }
-  bool match(char c) { if (p_ < end_ && *p_ == c) { ++p_; return true; } return false; }
-  void expect(char c) { if (!match(c)) err(std::string("Expected '") + c + "'"); }
-  bool word(const char* w) {
-    const size_t n = std::char_traits<char>::length(w);
-    if ((size_t)(end_ - p_) >= n && std::string(p_, n) == w) { p_ += n; return true; }
-    return false;
-  }
-  Json value() {
-    ws();
-    if (p_ >= end_) err("Unexpected end of input");
-    const char c = *p_;
-    Json v;
-    if (c == 'n') { if (!word("null")) err("Invalid token (expected null)"); return v; }
-    if (c == 't' || c == 'f') {
-      v.type = Json::T::Bool;
-      if (word("true")) v.b = true;
-      else if (word("false")) v.b = false;
-      else err("Invalid token (expected true/false)");
+  struct Scanner {
+    const char* cur;
+    const char* end;
+    [[noreturn]] void fail(const std::string& what) const { throw std::runtime_error("JSON parse error: " + what); }
+    bool at_end() const { return cur >= end; }
+    char peek() const { return *cur; }
+    void skip_space() { while (cur < end && std::isspace((unsigned char)*cur)) ++cur; }
+    bool take(char c) {
+      if (cur < end && *cur == c) { ++cur; return true; }
+      return false;
+    }
+    bool literal(const char* word) {
+      const size_t n = std::strlen(word);
+      if ((size_t)(end - cur) < n || std::memcmp(cur, word, n) != 0) return false;
+      cur += n;
+      return true;
+    }
+    static void append_utf8(std::string& out, unsigned cp) {  // code points below 0x10000 only (no surrogate pairing)
+      if (cp < 0x80) { out += (char)cp; return; }
+      if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); return; }
+      out += (char)(0xE0 | (cp >> 12));
+      out += (char)(0x80 | ((cp >> 6) & 0x3F));
+      out += (char)(0x80 | (cp & 0x3F));
+    }
+    std::string quoted() {
+      if (!take('"')) fail("Expected '\"'");
+      static const char kEsc[] = "\"\\/bfnrt", kRaw[] = "\"\\/\b\f\n\r\t";
+      std::string out;
+      while (cur < end) {
+        const char c = *cur++;
+        if (c == '"') return out;
+        if (c != '\\') { out += c; continue; }
+        if (cur >= end) fail("Bad escape");
+        const char e = *cur++;
+        if (e == 'u') {
+          if (end - cur < 4) fail("Bad \\u escape");
+          unsigned cp = 0;
+          for (int i = 0; i < 4; i++) {
+            const char h = cur[i];
+            const int d = (h >= '0' && h <= '9') ? h - '0' : (h >= 'a' && h <= 'f') ? h - 'a' + 10 : (h >= 'A' && h <= 'F') ? h - 'A' + 10 : -1;
+            if (d < 0) fail("Bad hex in \\u escape");
+            cp = cp * 16 + (unsigned)d;
+          }
+          cur += 4;
+          append_utf8(out, cp);
+          continue;
+        }
+        const char* hit = e ? std::strchr(kEsc, e) : nullptr;
+        if (!hit) fail("Unknown escape");
+        out += kRaw[hit - kEsc];
+      }
+      fail("Unterminated string");
+    }
+    // JSON number grammar, then strtod on exactly the matched characters
+    double number() {
+      const char* start = cur;
+      auto digits = [&]() { const char* s0 = cur; while (cur < end && *cur >= '0' && *cur <= '9') ++cur; return cur != s0; };
+      (void)take('-');
+      if (cur >= end) fail("Bad number");
+      if (*cur == '0') ++cur;
+      else if (!digits()) fail("Bad number");
+      if (take('.') && !digits()) fail("Bad fraction");
+      if (cur < end && (*cur == 'e' || *cur == 'E')) {
+        ++cur;
+        if (cur < end && (*cur == '+' || *cur == '-')) ++cur;
+        if (!digits()) fail("Bad exponent");
+      }
+      const std::string lexeme(start, cur);
+      char* stop = nullptr;
+      const double v = std::strtod(lexeme.c_str(), &stop);
+      if (stop == lexeme.c_str()) fail("Bad number conversion");
       return v;
     }
-    if (c == '"') { v.type = Json::T::Str; v.str = string(); return v; }
-    if (c == '{') return object();
-    if (c == '[') return array();
-    if (c == '-' || std::isdigit((unsigned char)c)) { v.type = Json::T::Num; v.num = number(); return v; }
-    err(std::string("Unexpected character '") + c + "'");
-  }
-  static int hex(char c) {
-    if (c >= '0' && c <= '9') return c - '0';
-    if (c >= 'a' && c <= 'f') return 10 + (c - 'a');
-    if (c >= 'A' && c <= 'F') return 10 + (c - 'A');
-    return -1;
-  }
-  std::string string() {
-    expect('"');
-    std::string out;
-    while (p_ < end_) {
-      const char c = *p_++;
-      if (c == '"') return out;
-      if (c != '\\') { out.push_back(c); continue; }
-      if (p_ >= end_) err("Bad escape");
-      const char e = *p_++;
-      switch (e) {
-        case '"': out.push_back('"'); break;
-        case '\\': out.push_back('\\'); break;
-        case '/': out.push_back('/'); break;
-        case 'b': out.push_back('\b'); break;
-        case 'f': out.push_back('\f'); break;
-        case 'n': out.push_back('\n'); break;
-        case 'r': out.push_back('\r'); break;
-        case 't': out.push_back('\t'); break;
-        case 'u': {
-          if (end_ - p_ < 4) err("Bad \\u escape");
-          int v = 0;
-          for (int i = 0; i < 4; i++) {
-            const int h = hex(p_[i]);
-            if (h < 0) err("Bad hex in \\u escape");
-            v = (v << 4) | h;
-          }
-          p_ += 4;
-          if (v <= 0x7F) out.push_back((char)v);
-          else if (v <= 0x7FF) { out.push_back((char)(0xC0 | ((v >> 6) & 0x1F))); out.push_back((char)(0x80 | (v & 0x3F))); }
-          else { out.push_back((char)(0xE0 | ((v >> 12) & 0x0F))); out.push_back((char)(0x80 | ((v >> 6) & 0x3F))); out.push_back((char)(0x80 | (v & 0x3F))); }
-          break;
-        }
-        default: err("Unknown escape");
-      }
-    }
-    err("Unterminated string");
-  }
-  double number() {
-    const char* start = p_;
-    (void)match('-');
-    if (p_ >= end_) err("Bad number");
-    if (*p_ == '0') ++p_;
-    else {
-      if (!std::isdigit((unsigned char)*p_)) err("Bad number");
-      while (p_ < end_ && std::isdigit((unsigned char)*p_)) ++p_;
-    }
-    if (p_ < end_ && *p_ == '.') {
-      ++p_;
-      if (p_ >= end_ || !std::isdigit((unsigned char)*p_)) err("Bad fraction");
-      while (p_ < end_ && std::isdigit((unsigned char)*p_)) ++p_;
-    }
-    if (p_ < end_ && (*p_ == 'e' || *p_ == 'E')) {
-      ++p_;
-      if (p_ < end_ && (*p_ == '+' || *p_ == '-')) ++p_;
-      if (p_ >= end_ || !std::isdigit((unsigned char)*p_)) err("Bad exponent");
-      while (p_ < end_ && std::isdigit((unsigned char)*p_)) ++p_;
-    }
-    const std::string tmp(start, p_);
-    char* ep = nullptr;
-    const double v = std::strtod(tmp.c_str(), &ep);
-    if (ep == tmp.c_str()) err("Bad number conversion");
-    return v;
-  }
-  Json array() {
-    expect('[');
-    Json out;
-    out.type = Json::T::Arr;
-    ws();
-    if (match(']')) return out;
-    while (true) {
-      out.arr.push_back(value());
-      ws();
-      if (match(']')) break;
-      expect(',');
-      ws();
-    }
-    return out;
-  }
-  Json object() {
-    expect('{');
-    Json out;
-    out.type = Json::T::Obj;
-    ws();
-    if (match('}')) return out;
-    while (true) {
-      if (p_ >= end_ || *p_ != '"') err("Expected string key");
-      std::string key = string();
-      ws();
-      expect(':');
-      ws();
-      Json v = value();
-      if (!out.get(key)) out.obj.emplace_back(std::move(key), std::move(v));
-      ws();
-      if (match('}')) break;
-      expect(',');
-      ws();
-    }
-    return out;
-  }
+  };
+  std::vector<Node> nodes_;
 };
 
-// T:65-106: cpp.* overrides common.*
-inline const Json* jget(const Json& v, std::initializer_list<const char*> path) {
-  const Json* cur = &v;
-  for (const char* k : path) {
-    cur = cur->get(k);
-    if (!cur) return nullptr;
-  }
-  return cur;
+// config lookup of the reference (T:65-106): cpp.<section>.<key> overrides common.<section>.<key>
+inline Json::Ref config_value(const Json& doc, const char* section, const char* key) {
+  for (const char* top : {"cpp", "common"})
+    if (Json::Ref v = doc.root().member(top).member(section).member(key)) return v;
+  return {};
 }
-inline const Json* jpick(const Json& root, const char* sec, const char* key) {
-  if (const Json* a = jget(root, {"cpp", sec, key})) return a;
-  return jget(root, {"common", sec, key});
-}
-inline std::optional<int> jint(const Json* v) {
-  if (v && v->type == Json::T::Num) return (int)std::llround(v->num);
+inline std::optional<double> as_number(Json::Ref v) {
+  if (v && v.node().kind == Json::Kind::Number) return v.node().number;
   return std::nullopt;
 }
-inline std::optional<double> jdouble(const Json* v) {
-  if (v && v->type == Json::T::Num) return v->num;
+inline std::optional<int> as_int(Json::Ref v) {  // T:84-88: llround
+  if (const auto d = as_number(v)) return (int)std::llround(*d);
   return std::nullopt;
 }
-inline std::optional<std::string> jstring(const Json* v) {
-  if (v && v->type == Json::T::Str) return v->str;
+inline std::optional<std::string> as_string(Json::Ref v) {
+  if (v && v.node().kind == Json::Kind::String) return v.node().text;
   return std::nullopt;
 }
 
@@ -251,34 +280,63 @@ struct Gray {
   int w = 0, h = 0;
   std::vector<std::uint8_t> pix;
 };
-// cpp/include/pgm_io.hpp:24-54
+
+// Binary PGM as the reference accepts it (cpp/include/pgm_io.hpp:24-54): "P5", width, height, maxval 255, ONE separator
+// byte, w*h pixels.  The reference reads the header with formatted stream extraction, and its quirks are part of the
+// surface: a '#' comment is only recognised where it starts directly behind the previous token (no newline in between);
+// a header number that does not parse leaves everything after it at 0, which surfaces as the maxval error.  Here the
+// file is read whole and scanned by hand with those rules.
 inline Gray read_pgm(const std::string& path) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) throw std::runtime_error("Failed to open: " + path);
-  auto skip_comments = [&]() {
-    while (f.peek() == '#') {
-      std::string line;
-      std::getline(f, line);
+  std::string bytes;
+  {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("Failed to open: " + path);
+    bytes.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  }
+  struct Header {
+    const std::string& s;
+    size_t at = 0;
+    bool failed = false;  // formatted extraction failed once: every later read yields 0 / nothing
+    void blanks() { while (at < s.size() && std::isspace((unsigned char)s[at])) ++at; }
+    std::string word() {
+      blanks();
+      const size_t b0 = at;
+      while (at < s.size() && !std::isspace((unsigned char)s[at])) ++at;
+      if (at == b0) failed = true;
+      return s.substr(b0, at - b0);
     }
-  };
-  std::string magic;
-  f >> magic;
-  if (magic != "P5") throw std::runtime_error("Only binary PGM (P5) supported: " + path);
-  skip_comments();
-  int w = 0, h = 0, maxv = 0;
-  f >> w;
-  skip_comments();
-  f >> h;
-  skip_comments();
-  f >> maxv;
-  if (maxv != 255) throw std::runtime_error("Only 8-bit PGM supported: " + path);
-  f.get();
+    void comments() {  // only a '#' that is the very next byte counts
+      while (!failed && at < s.size() && s[at] == '#') {
+        while (at < s.size() && s[at] != '\n') ++at;
+        if (at < s.size()) ++at;
+      }
+    }
+    int integer() {
+      if (failed) return 0;
+      blanks();
+      size_t p = at;
+      bool neg = false;
+      if (p < s.size() && (s[p] == '+' || s[p] == '-')) neg = s[p++] == '-';
+      long long v = 0;
+      const size_t d0 = p;
+      while (p < s.size() && s[p] >= '0' && s[p] <= '9' && v < (1ll << 40)) v = v * 10 + (s[p++] - '0');
+      if (p == d0 || v > 2147483647ll) { failed = true; return 0; }
+      at = p;
+      return (int)(neg ? -v : v);
+    }
+  } hd{bytes};
+  if (hd.word() != "P5") throw std::runtime_error("Only binary PGM (P5) supported: " + path);
+  hd.comments();
   Gray im;
-  im.w = w;
-  im.h = h;
-  im.pix.resize((size_t)w * (size_t)h);
-  f.read(reinterpret_cast<char*>(im.pix.data()), (std::streamsize)im.pix.size());
-  if (!f) throw std::runtime_error("PGM read failed: " + path);
+  im.w = hd.integer();
+  hd.comments();
+  im.h = hd.integer();
+  hd.comments();
+  if (hd.integer() != 255) throw std::runtime_error("Only 8-bit PGM supported: " + path);
+  const size_t body = hd.at + 1;  // exactly one separator byte
+  const size_t want = (im.w > 0 && im.h > 0) ? (size_t)im.w * (size_t)im.h : 0;
+  if (im.w < 0 || im.h < 0 || body > bytes.size() || bytes.size() - body < want) throw std::runtime_error("PGM read failed: " + path);
+  im.pix.assign(bytes.begin() + (std::ptrdiff_t)body, bytes.begin() + (std::ptrdiff_t)(body + want));
   return im;
 }
 

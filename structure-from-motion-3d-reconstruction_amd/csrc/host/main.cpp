@@ -5,7 +5,9 @@
 // --export-geometry mesh|both writes templeRing_mesh_sparse_kf<k>.ply through mesh.cpp (T:1884-1906).
 #include <cstdlib>
 #include <filesystem>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <optional>
 #include <string>
 
@@ -18,22 +20,158 @@ using namespace sfmx_cli;
 
 namespace {
 
-enum class ExportGeometry { NONE, POINTCLOUD, MESH, BOTH };
-std::optional<ExportGeometry> parse_export_geometry(const std::string& s) {  // T:42-51
-  if (s == "none") return ExportGeometry::NONE;
-  if (s == "pointcloud") return ExportGeometry::POINTCLOUD;
-  if (s == "mesh") return ExportGeometry::MESH;
-  if (s == "mesh_stereo") return ExportGeometry::MESH;
-  if (s == "both") return ExportGeometry::BOTH;
-  return std::nullopt;
+// ---- settings of one run and where each of them may come from ---------------------------------------------------
+// Precedence of the reference (T:1537-1676): command line > config "cpp" section > config "common" section > built-in
+// default.  Every setting is one row of a table: its command-line flag (if it has one), its config.json location (if it
+// has one) and a typed slot; parsing and the config overlay are loops over the tables.
+enum class Geometry { None, PointCloud, Mesh, Both };
+
+bool geometry_from_name(const std::string& name, Geometry& out) {  // accepted spellings: T:42-51
+  static const std::pair<const char*, Geometry> names[] = {{"none", Geometry::None}, {"pointcloud", Geometry::PointCloud}, {"mesh", Geometry::Mesh},
+                                                            {"mesh_stereo", Geometry::Mesh}, {"both", Geometry::Both}};
+  for (const auto& kv : names)
+    if (name == kv.first) { out = kv.second; return true; }
+  return false;
 }
 
-std::string read_text_file(const fs::path& p) {
-  std::ifstream f(p);
-  if (!f) throw std::runtime_error("Failed to open: " + p.string());
-  std::ostringstream ss;
-  ss << f.rdbuf();
-  return ss.str();
+struct Settings {
+  int frames = 12;
+  Geometry geometry = Geometry::PointCloud;
+  int mesh_kf = 0, mesh_max_points = 2500, mesh_grid_px = 4;
+  double mesh_max_edge_px = 80.0;
+  PipelineConfig pipe;
+  std::string config_path;
+  bool config_given = false;
+};
+
+// a typed destination inside Settings
+struct Slot {
+  enum Type { Int, Real, GeometryName, Path } type;
+  void* at;
+  void from_text(const std::string& text, const std::string& flag) const {  // command-line value
+    switch (type) {
+      case Int: *static_cast<int*>(at) = std::stoi(text); break;
+      case Real: *static_cast<double*>(at) = std::stod(text); break;
+      case Path: *static_cast<std::string*>(at) = text; break;
+      case GeometryName:
+        if (!geometry_from_name(text, *static_cast<Geometry*>(at))) throw std::runtime_error("Invalid " + flag + " value: " + text);
+        break;
+    }
+  }
+  void from_config(Json::Ref v) const {  // a value of the wrong JSON type is ignored, as in the reference's getters (T:84-106)
+    switch (type) {
+      case Int: if (const auto i = as_int(v)) *static_cast<int*>(at) = *i; break;
+      case Real: if (const auto d = as_number(v)) *static_cast<double*>(at) = *d; break;
+      case GeometryName: if (const auto t = as_string(v)) (void)geometry_from_name(*t, *static_cast<Geometry*>(at)); break;
+      case Path: break;
+    }
+  }
+};
+struct Row {
+  const char* flag;     // command-line spelling or nullptr
+  const char* section;  // config.json section under "cpp" / "common", or nullptr
+  const char* key;
+  Slot slot;
+  bool set_on_cli = false;
+};
+
+std::vector<Row> setting_rows(Settings& s) {
+  PipelineConfig& p = s.pipe;
+  return {
+      {"--config", nullptr, nullptr, {Slot::Path, &s.config_path}},
+      {"--export-geometry", "outputs", "export_geometry", {Slot::GeometryName, &s.geometry}},
+      {"--mesh-kf", "mesh_sparse", "kf", {Slot::Int, &s.mesh_kf}},
+      {"--mesh-max-points", "mesh_sparse", "max_points", {Slot::Int, &s.mesh_max_points}},
+      {"--mesh-grid-px", "mesh_sparse", "grid_px", {Slot::Int, &s.mesh_grid_px}},
+      {"--mesh-max-edge-px", "mesh_sparse", "max_edge_px", {Slot::Real, &s.mesh_max_edge_px}},
+      {nullptr, "system", "frames", {Slot::Int, &s.frames}},  // the command line gives it as the third positional
+      {nullptr, "klt", "max_tracks", {Slot::Int, &p.klt.max_tracks}},
+      {nullptr, "klt", "min_tracks", {Slot::Int, &p.klt.min_tracks}},
+      {nullptr, "klt", "quality", {Slot::Real, &p.klt.quality}},
+      {nullptr, "klt", "min_distance", {Slot::Int, &p.klt.min_distance}},
+      {nullptr, "klt", "pyr_levels", {Slot::Int, &p.klt.pyr_levels}},
+      {nullptr, "klt", "win_radius", {Slot::Int, &p.klt.win_radius}},
+      {nullptr, "klt", "iters", {Slot::Int, &p.klt.iters}},
+      {nullptr, "klt", "fb_thresh", {Slot::Real, &p.klt.fb_thresh}},
+      {nullptr, "keyframe", "min_gap", {Slot::Int, &p.kf_min_gap}},
+      {nullptr, "keyframe", "min_inliers", {Slot::Int, &p.kf_min_inliers}},
+      {nullptr, "keyframe", "parallax_px", {Slot::Real, &p.kf_parallax_px}},
+      {nullptr, "ba", "window", {Slot::Int, &p.ba.window}},
+      {nullptr, "ba", "iters", {Slot::Int, &p.ba.iters}},
+      {nullptr, "ba", "max_points", {Slot::Int, &p.ba.max_points}},
+      {nullptr, "ba", "huber_delta", {Slot::Real, &p.ba.huber_delta}},
+      {nullptr, "ba", "lambda", {Slot::Real, &p.ba.lambda}},
+  };
+}
+
+void print_usage(const char* argv0) {  // text of T:1521-1534
+  std::cerr << "Usage: " << argv0 << " <templering_root> <out_dir> [frames] [options]\n"
+            << "Input must be PGM images (P5) in <templering_root>/templeRing_pgm/\n"
+            << "and par/ang files in <templering_root>/templeRing/.\n\n"
+            << "Options:\n"
+            << "  --config <path>           Config JSON (defaults to ./config.json when present)\n"
+            << "  --export-geometry <none|pointcloud|mesh|both>\n"
+            << "      none: no .ply geometry outputs\n"
+            << "      pointcloud: write templeRing_sparse_points.ply\n"
+            << "      mesh: write templeRing_mesh_sparse_kf<k>.ply (2D Delaunay on projected sparse points)\n"
+            << "      both: write both pointcloud and mesh\n"
+            << "  --mesh-kf <k>            Keyframe index used for 2D projection (default 0)\n"
+            << "  --mesh-max-points <n>    Max vertices in mesh (default 2500)\n"
+            << "  --mesh-grid-px <px>      Pixel grid subsampling cell size (default 4)\n"
+            << "  --mesh-max-edge-px <px>  Reject triangles with any edge longer than this (default 80)\n";
+}
+
+// Fills `s` from argv[3..] and the config file.  Returns false when --help ended the run (exit code 0).
+bool gather_settings(int argc, char** argv, Settings& s) {
+  std::vector<Row> rows = setting_rows(s);
+  std::vector<std::string> args(argv + 3, argv + argc);
+  size_t at = 0;
+  bool frames_on_cli = false;
+  if (!args.empty() && !args[0].empty() && args[0][0] != '-') {  // optional third positional: frames (T:1546-1553)
+    s.frames = std::stoi(args[0]);
+    frames_on_cli = true;
+    at = 1;
+  }
+  while (at < args.size()) {
+    const std::string& flag = args[at++];
+    if (flag == "-h" || flag == "--help") {
+      std::cerr << "Run without args to see usage.\n";
+      return false;
+    }
+    Row* row = nullptr;
+    for (Row& r : rows)
+      if (r.flag && flag == r.flag) row = &r;
+    if (!row) throw std::runtime_error("Unknown option: " + flag);
+    if (at >= args.size()) throw std::runtime_error("Missing value for " + flag);
+    row->slot.from_text(args[at++], flag);
+    row->set_on_cli = true;
+  }
+  s.config_given = rows[0].set_on_cli;
+  if (!s.config_given && fs::exists("config.json")) {  // auto-discovery in the working directory (T:1613-1619)
+    s.config_path = "config.json";
+    s.config_given = true;
+  }
+  if (!s.config_given) return true;
+  Json doc;
+  try {
+    std::ifstream f(s.config_path);
+    if (!f) throw std::runtime_error("Failed to open: " + s.config_path);
+    std::ostringstream text;
+    text << f.rdbuf();
+    doc = Json::parse(text.str());
+  } catch (const std::exception& e) {
+    throw std::runtime_error("Failed to parse config.json: " + s.config_path + " | " + e.what());
+  }
+  for (const Row& r : rows) {
+    if (!r.section || r.set_on_cli) continue;
+    if (r.slot.at == &s.frames) {
+      if (frames_on_cli) continue;
+      if (const auto v = as_int(config_value(doc, r.section, r.key))) s.frames = std::max(1, *v);  // T:1633-1635
+      continue;
+    }
+    r.slot.from_config(config_value(doc, r.section, r.key));
+  }
+  return true;
 }
 
 // frames read lazily from <root>/templeRing_pgm/<stem>.pgm, exactly when the reference reads them
@@ -63,105 +201,18 @@ int main(int argc, char** argv) {
   setenv("GPU_MAX_HW_QUEUES", "8", 0);
   try {
     if (argc < 3) {
-      std::cerr << "Usage: " << argv[0] << " <templering_root> <out_dir> [frames] [options]\n"
-                << "Input must be PGM images (P5) in <templering_root>/templeRing_pgm/\n"
-                << "and par/ang files in <templering_root>/templeRing/.\n\n"
-                << "Options:\n"
-                << "  --config <path>           Config JSON (defaults to ./config.json when present)\n"
-                << "  --export-geometry <none|pointcloud|mesh|both>\n"
-                << "      none: no .ply geometry outputs\n"
-                << "      pointcloud: write templeRing_sparse_points.ply\n"
-                << "      mesh: write templeRing_mesh_sparse_kf<k>.ply (2D Delaunay on projected sparse points)\n"
-                << "      both: write both pointcloud and mesh\n"
-                << "  --mesh-kf <k>            Keyframe index used for 2D projection (default 0)\n"
-                << "  --mesh-max-points <n>    Max vertices in mesh (default 2500)\n"
-                << "  --mesh-grid-px <px>      Pixel grid subsampling cell size (default 4)\n"
-                << "  --mesh-max-edge-px <px>  Reject triangles with any edge longer than this (default 80)\n";
+      print_usage(argv[0]);
       return 2;
     }
     const fs::path root = fs::path(argv[1]);
     const fs::path out = fs::path(argv[2]);
-    int frames = 12;
-    bool frames_from_cli = false;
-    fs::path config_path;
-    bool have_config = false;
-    int argi = 3;
-    if (argc >= 4) {
-      const std::string a3 = argv[3];
-      if (!a3.empty() && a3[0] != '-') {
-        frames = std::stoi(a3);
-        frames_from_cli = true;
-        argi = 4;
-      }
-    }
-    ExportGeometry export_geom = ExportGeometry::POINTCLOUD;
-    bool export_geom_from_cli = false;
-    int mesh_kf = 0, mesh_max_points = 2500, mesh_grid_px = 4;
-    double mesh_max_edge_px = 80.0;
-    bool mesh_kf_cli = false, mesh_max_points_cli = false, mesh_grid_px_cli = false, mesh_max_edge_px_cli = false;
-    PipelineConfig pc;
-    while (argi < argc) {
-      const std::string flag = argv[argi++];
-      auto need = [&](const std::string& name) -> std::string {
-        if (argi >= argc) throw std::runtime_error("Missing value for " + name);
-        return std::string(argv[argi++]);
-      };
-      if (flag == "--config") { config_path = fs::path(need(flag)); have_config = true; }
-      else if (flag == "--export-geometry") {
-        const std::string v = need(flag);
-        const auto eg = parse_export_geometry(v);
-        if (!eg) throw std::runtime_error("Invalid --export-geometry value: " + v);
-        export_geom = *eg;
-        export_geom_from_cli = true;
-      }
-      else if (flag == "--mesh-kf") { mesh_kf = std::stoi(need(flag)); mesh_kf_cli = true; }
-      else if (flag == "--mesh-max-points") { mesh_max_points = std::stoi(need(flag)); mesh_max_points_cli = true; }
-      else if (flag == "--mesh-grid-px") { mesh_grid_px = std::stoi(need(flag)); mesh_grid_px_cli = true; }
-      else if (flag == "--mesh-max-edge-px") { mesh_max_edge_px = std::stod(need(flag)); mesh_max_edge_px_cli = true; }
-      else if (flag == "-h" || flag == "--help") { std::cerr << "Run without args to see usage.\n"; return 0; }
-      else throw std::runtime_error("Unknown option: " + flag);
-    }
-    if (!have_config) {
-      const fs::path local = fs::path("config.json");
-      if (fs::exists(local)) { config_path = local; have_config = true; }
-    }
-    std::optional<Json> cfg;
-    if (have_config) {
-      try {
-        cfg = JsonParser(read_text_file(config_path)).parse();
-      } catch (const std::exception& e) {
-        throw std::runtime_error("Failed to parse config.json: " + config_path.string() + " | " + e.what());
-      }
-    }
-    if (cfg) {  // T:1631-1676
-      if (!frames_from_cli)
-        if (auto v = jint(jpick(*cfg, "system", "frames"))) frames = std::max(1, *v);
-      if (!export_geom_from_cli)
-        if (auto s = jstring(jpick(*cfg, "outputs", "export_geometry")))
-          if (const auto eg = parse_export_geometry(*s)) export_geom = *eg;
-      if (!mesh_kf_cli) if (auto v = jint(jpick(*cfg, "mesh_sparse", "kf"))) mesh_kf = *v;  // T:1642-1653
-      if (!mesh_max_points_cli) if (auto v = jint(jpick(*cfg, "mesh_sparse", "max_points"))) mesh_max_points = *v;
-      if (!mesh_grid_px_cli) if (auto v = jint(jpick(*cfg, "mesh_sparse", "grid_px"))) mesh_grid_px = *v;
-      if (!mesh_max_edge_px_cli) if (auto v = jdouble(jpick(*cfg, "mesh_sparse", "max_edge_px"))) mesh_max_edge_px = *v;
-      if (auto v = jint(jpick(*cfg, "klt", "max_tracks"))) pc.klt.max_tracks = *v;
-      if (auto v = jint(jpick(*cfg, "klt", "min_tracks"))) pc.klt.min_tracks = *v;
-      if (auto v = jdouble(jpick(*cfg, "klt", "quality"))) pc.klt.quality = *v;
-      if (auto v = jint(jpick(*cfg, "klt", "min_distance"))) pc.klt.min_distance = *v;
-      if (auto v = jint(jpick(*cfg, "klt", "pyr_levels"))) pc.klt.pyr_levels = *v;
-      if (auto v = jint(jpick(*cfg, "klt", "win_radius"))) pc.klt.win_radius = *v;
-      if (auto v = jint(jpick(*cfg, "klt", "iters"))) pc.klt.iters = *v;
-      if (auto v = jdouble(jpick(*cfg, "klt", "fb_thresh"))) pc.klt.fb_thresh = *v;
-      if (auto v = jint(jpick(*cfg, "keyframe", "min_gap"))) pc.kf_min_gap = *v;
-      if (auto v = jint(jpick(*cfg, "keyframe", "min_inliers"))) pc.kf_min_inliers = *v;
-      if (auto v = jdouble(jpick(*cfg, "keyframe", "parallax_px"))) pc.kf_parallax_px = *v;
-      if (auto v = jint(jpick(*cfg, "ba", "window"))) pc.ba.window = *v;
-      if (auto v = jint(jpick(*cfg, "ba", "iters"))) pc.ba.iters = *v;
-      if (auto v = jint(jpick(*cfg, "ba", "max_points"))) pc.ba.max_points = *v;
-      if (auto v = jdouble(jpick(*cfg, "ba", "huber_delta"))) pc.ba.huber_delta = *v;
-      if (auto v = jdouble(jpick(*cfg, "ba", "lambda"))) pc.ba.lambda = *v;
-    }
+    Settings st;
+    if (!gather_settings(argc, argv, st)) return 0;
+    PipelineConfig& pc = st.pipe;
+    const int frames = st.frames;
     pc.frames = frames;
-    pc.export_pointcloud = (export_geom == ExportGeometry::POINTCLOUD || export_geom == ExportGeometry::BOTH);
+    pc.export_pointcloud = st.geometry == Geometry::PointCloud || st.geometry == Geometry::Both;
+    const bool want_mesh = st.geometry == Geometry::Mesh || st.geometry == Geometry::Both;
 
     const fs::path par = root / "templeRing" / "templeR_par.txt";
     const fs::path ang = root / "templeRing" / "templeR_ang.txt";
@@ -197,16 +248,16 @@ int main(int argc, char** argv) {
     run_pipeline(ctx, src, meta, K, pc, res, echo_line);
     const size_t printed = res.log.size();
     write_outputs(out.string(), pc, meta, res);
-    if (export_geom == ExportGeometry::MESH || export_geom == ExportGeometry::BOTH) {  // T:1884-1906
+    if (want_mesh) {  // T:1884-1906
       if (res.kfs.empty()) {
         std::cerr << "WARN: mesh export skipped (no keyframes).\n";
       } else {
-        const int kidx = std::max(0, std::min(mesh_kf, (int)res.kfs.size() - 1));
+        const int kidx = std::max(0, std::min(st.mesh_kf, (int)res.kfs.size() - 1));
         const Keyframe& mkf = res.kfs[(size_t)kidx];
         const Gray im = read_pgm((src.dir / fs::path(mkf.img_name).replace_extension(".pgm")).string());  // its size bounds the projection
         std::vector<V3> verts;
         std::vector<std::array<int, 3>> faces;
-        build_sparse_mesh(K, mkf.pose, res.map, im.w, im.h, mesh_max_points, mesh_grid_px, mesh_max_edge_px, verts, faces);
+        build_sparse_mesh(K, mkf.pose, res.map, im.w, im.h, st.mesh_max_points, st.mesh_grid_px, st.mesh_max_edge_px, verts, faces);
         if (verts.empty() || faces.empty()) std::cerr << "WARN: mesh export skipped (insufficient projected points or no valid triangles).\n";
         else write_mesh_ply((out / (std::string("templeRing_mesh_sparse_kf") + std::to_string(kidx) + ".ply")).string(), verts, faces);
       }

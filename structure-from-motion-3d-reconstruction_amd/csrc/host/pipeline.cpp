@@ -2,6 +2,7 @@
 #include "pipeline.hpp"
 
 #include "../hip/sfmx_math.h"
+#include "cli_io.hpp"
 #include "introsort_replay.hpp"
 #include "thread_pool.hpp"
 
@@ -1761,6 +1762,38 @@ int sfmx_host_tracker_tracks(void* h, double* xy, int* ids, int cap) {  // KLTTr
   if (n > cap) return -SFMX_ERR_INVALID;
   for (int i = 0; i < n; i++) { xy[2 * i] = tr[(size_t)i].p.x; xy[2 * i + 1] = tr[(size_t)i].p.y; ids[i] = tr[(size_t)i].id; }
   return n;
+}
+
+// the CLI's file readers on their own (csrc/host/cli_io.hpp), for the surface tests against the reference's readers
+int sfmx_host_read_pgm(const char* path, int* w, int* h, unsigned long long* checksum, char* err, int cap) {
+  try {
+    const sfmx_cli::Gray im = sfmx_cli::read_pgm(path);
+    *w = im.w;
+    *h = im.h;
+    unsigned long long s = 0;
+    for (size_t i = 0; i < im.pix.size(); i++) s += (unsigned long long)im.pix[i] * (i % 251 + 1);
+    *checksum = s;
+    return 0;
+  } catch (const std::exception& e) {
+    std::snprintf(err, (size_t)cap, "%s", e.what());
+    return 1;
+  }
+}
+// kind 0 = int, 1 = double, 2 = string.  1 = found, 0 = absent or of another type, -1 = parse error (message in text_out)
+int sfmx_host_config_lookup(const char* json, const char* section, const char* key, int kind, double* num_out, char* text_out, int cap) {
+  try {
+    const sfmx_cli::Json doc = sfmx_cli::Json::parse(json);
+    const sfmx_cli::Json::Ref v = sfmx_cli::config_value(doc, section, key);
+    if (kind == 0) { const auto r = sfmx_cli::as_int(v); if (!r) return 0; *num_out = *r; return 1; }
+    if (kind == 1) { const auto r = sfmx_cli::as_number(v); if (!r) return 0; *num_out = *r; return 1; }
+    const auto r = sfmx_cli::as_string(v);
+    if (!r) return 0;
+    std::snprintf(text_out, (size_t)cap, "%s", r->c_str());
+    return 1;
+  } catch (const std::exception& e) {
+    std::snprintf(text_out, (size_t)cap, "%s", e.what());
+    return -1;
+  }
 }
 
 // host-side math self-checks used by the CPU test-suite (no device involved)

@@ -2,6 +2,7 @@
 host by design) against the golden vectors from the reference build.  No device calls."""
 import ctypes
 import importlib
+import os
 
 import numpy as np
 
@@ -141,3 +142,67 @@ def test_sparse_mesh_matches_reference():
         assert nv == len(g[name + "_v"]) and int(nf[0]) == len(g[name + "_f"]), name
         H.assert_bits_equal(v[:nv], g[name + "_v"], f"mesh vertices ({name})")
         assert np.array_equal(f[:int(nf[0])], g[name + "_f"]), name
+
+
+# ------------------------------------------------------------------ file-format surface of the CLI (csrc/host/cli_io.hpp)
+def _surface():
+    import json
+    return json.load(open(os.path.join(H.GOLDEN, "surface_cases.json")))
+
+
+def test_read_pgm_matches_reference_reader(tmp_path):
+    """PGM header comments, maxval != 255, short files, odd separators (cpp/include/pgm_io.hpp:24-54): size, pixels and
+    error text of the product's reader vs what the compiled reference reader did (tests/golden/make_surface_golden.py)."""
+    import base64
+    import ctypes
+    host = L.dll
+    path = str(tmp_path / "f.pgm")
+    for c in _surface()["pgm"]:
+        with open(path, "wb") as f:
+            f.write(base64.b64decode(c["data"]))
+        w, h, cs = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_ulonglong(0)
+        err = ctypes.create_string_buffer(512)
+        rc = host.sfmx_host_read_pgm(path.encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(cs), err, 512)
+        msg = err.value.decode().replace(path, "<PATH>")
+        if c["ub"]:  # the reference reads uninitialised ints here: it fails, with one of its two later error texts
+            assert rc == 1 and msg in ("Only 8-bit PGM supported: <PATH>", "PGM read failed: <PATH>"), (c["name"], msg)
+            continue
+        assert rc == c["rc"], (c["name"], msg)
+        if rc == 0:
+            assert (w.value, h.value, cs.value) == (c["w"], c["h"], c["checksum"]), c["name"]
+        else:
+            assert msg == c["error"], c["name"]
+
+
+def test_config_json_matches_reference_reader():
+    """config.json lookups (cpp.* over common.*, llround, type mismatches, duplicate keys, escapes) and every parse-error
+    text: the product's reader vs minijson + the getters of templering_sfm.cpp (T:65-106) compiled from the reference."""
+    import base64
+    import ctypes
+    host = L.dll
+    for c in _surface()["json"]:
+        num = ctypes.c_double(0)
+        buf = ctypes.create_string_buffer(512)
+        rc = host.sfmx_host_config_lookup(c["text"].encode(), c["section"].encode(), c["key"].encode(), c["kind"], ctypes.byref(num), buf, 512)
+        assert rc == c["rc"], (c["name"], rc, buf.value)
+        if rc == 1 and c["kind"] < 2:
+            assert num.value == c["number"], c["name"]
+        if (rc == 1 and c["kind"] == 2) or rc == -1:
+            assert buf.value == base64.b64decode(c["string"]), (c["name"], buf.value)
+
+
+def test_cli_argument_and_config_errors_match_reference_cli(tmp_path):
+    """Everything the CLI reports BEFORE it needs the device -- usage / help / unknown option / missing value / invalid
+    enum / unreadable or malformed config / missing par file / unreadable first image (T:1518-1711) -- against the text and
+    exit code of the compiled reference CLI (tests/golden/surface_cases.json)."""
+    import subprocess
+    g = _surface()["cli"]
+    for rel, text in g["files"].items():
+        os.makedirs(os.path.dirname(str(tmp_path / rel)), exist_ok=True)
+        (tmp_path / rel).write_text(text)
+    assert os.path.exists(pipe.CLI_PATH), "run __graft_entry__.build() first"
+    for c in g["cases"]:
+        p = subprocess.run([pipe.CLI_PATH] + c["args"], cwd=str(tmp_path), capture_output=True, text=True)
+        assert p.returncode == c["rc"], (c["args"], p.stderr)
+        assert p.stdout == c["stdout"], c["args"]
+        assert p.stderr.replace(pipe.CLI_PATH, "<CLI>") == c["stderr"], c["args"]
