@@ -78,6 +78,88 @@ def cpu_baseline(seq, cfg, sample_frames: int):
                 frames_per_s=sample_frames / dt)
 
 
+def bench_ba_sharded(args, capi, synth, rank, local_rank, world):
+    """BASELINE config C4: local BA on W=10 poses, P=50 000 points, every point seen by every pose (500 k residuals), points
+    sharded over the ranks; a step = one BA iteration = partial build of S|b on this rank's points, RCCL all-reduce(sum) of
+    D*D + D = 3 660 doubles in HBM, damping + gauge, dense solve on the device, dx to the host."""
+    import torch
+    import torch.distributed as dist
+    D = importlib.import_module(PKG + ".dist")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    W, P = 10, 50000
+    rng = np.random.default_rng(1)
+    pw = np.zeros((W, 12))
+    for k in range(W):
+        R, t = synth.ring_pose(2.0 * k)
+        pw[k, :9], pw[k, 9:] = R.ravel(), t
+    K = synth.K_TEMPLE
+    X = rng.normal(size=(P, 3)) * 0.08
+    ptr = np.arange(0, (P + 1) * W, W, dtype=np.int32)
+    li = np.tile(np.arange(W, dtype=np.int32), P)
+    Xc = np.einsum("kij,pj->pki", pw[:, :9].reshape(W, 3, 3), X) + pw[None, :, 9:]
+    uv = np.stack([K[0, 0] * Xc[..., 0] / Xc[..., 2] + K[0, 2], K[1, 1] * Xc[..., 1] / Xc[..., 2] + K[1, 2]], -1)
+    uv = np.ascontiguousarray((uv + rng.normal(size=uv.shape) * 0.5).reshape(P * W, 2))
+    ctx = capi.Context(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm = D.make_comms(1, local_rank)[0]
+    lo, hi = capi.shard_range(P, rank, world)
+    o0, o1 = int(ptr[lo]), int(ptr[hi])
+    prob = ctx.ba_problem(W, X[lo:hi], ptr[lo:hi + 1] - o0, li[o0:o1], uv[o0:o1])
+    a = (pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        rc, dx = prob.step_sharded(comm, *a)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rc, dx = prob.step_sharded(comm, *a)
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ctx.set_timing(True)
+    for _ in range(3):
+        prob.step_sharded(comm, *a)
+    prof = {k: v for k, v in ctx.kernel_profile().items() if v[1] > 0}
+    ctx.set_timing(False)
+    if rank == 0:
+        Pl, R = hi - lo, (hi - lo) * W
+        dom = max(prof, key=lambda k: prof[k][0])
+        avg_us = prof[dom][0] / prof[dom][1]
+        # algorithmic figures of SURVEY.md 8(d) for THIS rank's shard: 535 flop per residual + (126 n + 180 n^2 + 40) per point (n = W)
+        flop = {"k_ba_points": 535.0 * R + Pl * (126.0 * W + 180.0 * W * W + 40.0), "k_ba_reduce": 1.0 * Pl * (36 * W * W + 6 * W)}
+        byts = {"k_ba_points": 20.0 * R + 24.0 * Pl + 96.0 * W, "k_ba_reduce": 8.0 * Pl * (36 * W * W + 48 * W),
+                "k_ba_expand": 2 * 8.0 * Pl * (36 * W * W + 48 * W)}
+        ach_gbs = byts[dom] / (avg_us * 1e-6) / 1e9 if dom in byts else None
+        out = {"metric": "BA iterations/sec, BASELINE config C4 (W=10 poses, P=50 000 points, 500 k residuals), points sharded over the ranks",
+               "value": round(args.steps / dt, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "mode": "ba-sharded",
+               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "local BA S|b build + reduce + dense solve, W=10, P=50000, every point in every pose, N(0,0.5 px) noise",
+                          "points_per_rank": Pl, "allreduce_doubles": 60 * 60 + 60, "parallelism": f"BA points x{world}, RCCL all-reduce(sum) of S|b in HBM"},
+               "roofline": {"bound": "hbm", "achieved": None if ach_gbs is None else round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": None if ach_gbs is None else round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": None, "kernel": dom,
+                            "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(byts.get(dom, 0)),
+                            "kernel_us_per_step": {k: round(v[0] / v[1], 2) for k, v in prof.items()}},
+               "dx_head": [float(v) for v in dx[6:9]]}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    prob.close()
+    comm.close()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +175,11 @@ def main():
     ap.add_argument("--batched-probe", type=int, default=3,
                     help="after the headline measurement (1 sequence per GPU) also time this many sequences in flight and "
                          "report it as `batched` (single-GPU runs only; 0 = skip)")
+    ap.add_argument("--mode", choices=("sequences", "ba-sharded", "sharded-sequence"), default="sequences",
+                    help="sequences (headline): one independent sequence per rank, weak scaling, no data-path collective; "
+                         "ba-sharded: BASELINE config C4 (W=10, P=50 000, 500 k residuals) with the points sharded over the ranks and one "
+                         "RCCL all-reduce of S|b per iteration (strong scaling); sharded-sequence: ONE sequence on all ranks, BA points "
+                         "and RANSAC hypotheses sharded (strong scaling)")
     args = ap.parse_args()
 
     import torch
@@ -110,6 +197,8 @@ def main():
     capi = importlib.import_module(PKG + ".capi")
     pipe = importlib.import_module(PKG + ".pipeline")
     synth = importlib.import_module(PKG + ".synth")
+    if args.mode == "ba-sharded":
+        return bench_ba_sharded(args, capi, synth, rank, local_rank, world)
 
     # --- synthetic TempleRing-47 stand-in: S independent sequences per rank, each with its own context and host thread
     # (one sequence alone cannot fill the device: its kernels are short dependent chains)
@@ -122,7 +211,8 @@ def main():
     def ensure_sequences(n):  # contexts are created only when used: idle streams still take part in the HW-queue mapping
         while len(seqs) < n:
             q = len(seqs)
-            seqs.append(synth.make_sequence(args.frames, 640, 480, args.deg_per_frame, n_blobs=20000, seed=7 + rank + 101 * q))
+            seed = 7 + 101 * q + (0 if args.mode == "sharded-sequence" else rank)  # sharded-sequence: every rank holds THE sequence
+            seqs.append(synth.make_sequence(args.frames, 640, 480, args.deg_per_frame, n_blobs=20000, seed=seed))
             ctxs.append(capi.Context(local_rank))
             devs.append(torch.from_numpy(np.ascontiguousarray(seqs[q]["images"])).to(f"cuda:{local_rank}"))  # resident in HBM
         torch.cuda.synchronize()
@@ -131,9 +221,11 @@ def main():
     seq, ctx, frames_dev = seqs[0], ctxs[0], devs[0]
     shape = tuple(frames_dev.shape)
 
+    comms = None  # sharded-sequence: three native RCCL communicators (BA lane, frame->frame RANSAC lane, keyframe RANSAC lane)
+
     def one_pass(timing=False, q=0):
         return pipe.run(ctxs[q], None, seqs[q]["names"], seqs[q]["K"], seqs[q]["lat"], seqs[q]["lon"], cfg, None,
-                        images_dev=devs[q].data_ptr(), shape=shape, timing=timing)
+                        images_dev=devs[q].data_ptr(), shape=shape, timing=timing, comms=comms)
 
     def barrier():
         if world > 1:
@@ -145,6 +237,8 @@ def main():
     one_pass()
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.mode == "sharded-sequence":
+        comms = tuple(importlib.import_module(PKG + ".dist").make_comms(3, local_rank))
 
     def measure(n_seq, n_warm, n_steps):
         """n_seq sequences in flight (one host thread + context each): wall time of n_steps passes of every sequence.
@@ -194,9 +288,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        k = torch.tensor([kf_total], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(k, op=dist.ReduceOp.SUM)
-        kf_total = int(k.item())
+        if args.mode != "sharded-sequence":  # there every rank reports the keyframes of the same one job
+            k = torch.tensor([kf_total], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(k, op=dist.ReduceOp.SUM)
+            kf_total = int(k.item())
 
     # --- one extra, untimed pass with per-kernel HIP-event timing for the roofline object
     prof = one_pass(timing=True)["stats"]
@@ -269,14 +364,16 @@ def main():
         out = {
             "metric": "keyframes/sec (KLT + RANSAC + local BA per-frame loop), synthetic TempleRing-47 stand-in",
             "value": round(kf_total / dt, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if args.mode == "sharded-sequence" else "weak", "mode": args.mode, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic TempleRing-47 stand-in: {args.frames} frames 640x480 u8, ring camera {args.deg_per_frame} deg/frame, "
                                    f"reference default config (max_tracks={args.max_tracks}, RANSAC 2500 iters, BA window 6 / 600 pts / 5 iters); "
                                    f"{S} independent sequence(s) in flight per GPU", "frames_per_step": args.frames * S, "sequences_per_gpu": S,
-                       "parallelism": f"sequences x{world * S}"},
-            "frames_per_s": round(args.frames * args.steps * world * S / dt, 2),
-            "keyframes_per_step": int(round(kf_total / max(1, args.steps) / world)), "map_points": st["n_points"], "passes_bit_identical": bool(identical),
+                       "parallelism": (f"one sequence on {world} ranks: BA points + RANSAC hypotheses sharded, RCCL all-reduce"
+                                       if args.mode == "sharded-sequence" else f"sequences x{world * S}")},
+            "frames_per_s": round(args.frames * args.steps * (1 if args.mode == "sharded-sequence" else world) * S / dt, 2),
+            "keyframes_per_step": int(round(kf_total / max(1, args.steps) / (1 if args.mode == "sharded-sequence" else world))), "map_points": st["n_points"], "passes_bit_identical": bool(identical),
             "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_wall", "sec_total", "sec_setup", "sec_klt", "sec_shi", "sec_shi_wait", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_pf_busy", "sec_pf_gpu", "sec_pf_replay", "sec_lane_a_busy", "sec_lane_b_busy", "sec_lane_c_busy", "sec_join_wait", "sec_ba_gather", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_feed_wait")},
             "counters_per_step": {k: int(st[k]) for k in ("klt_calls", "tracks_in", "lk_steps", "ransac_calls", "ransac_points", "ransac_verified", "ransac_cert_misses", "ba_calls", "ba_iters", "shi_calls", "shi_memo_hits", "shi_prefetched", "shi_fallbacks")},
             "roofline": roofline,

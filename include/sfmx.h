@@ -172,6 +172,30 @@ int sfmx_ba_step(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, d
 int sfmx_ba_build_partial(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, double fx,
                           double fy, double cx, double cy, double huber, void** S_dev, void** b_dev);
 
+/* ---- multi-GPU exchange steps (one process per GPU, RCCL over xGMI) ---------------------------- */
+/* The reference is single-process; these are the collectives the sharded modes of this library add.
+ * A communicator belongs to ONE host thread / context at a time (a pipeline uses one per lane).  world == 1 (or a NULL
+ * communicator) makes every call below a local no-op, so the sharded entry points can be used unconditionally. */
+typedef struct sfmx_comm sfmx_comm;
+#define SFMX_COMM_ID_BYTES 128
+int sfmx_comm_get_unique_id(void* id_out);  /* rank 0; the application carries the 128 bytes to the other ranks */
+int sfmx_comm_create(int device_id, const void* id_bytes, int rank, int world, sfmx_comm** out);
+void sfmx_comm_destroy(sfmx_comm* comm);
+int sfmx_comm_rank(const sfmx_comm* comm);
+int sfmx_comm_world(const sfmx_comm* comm);
+/* contiguous, order-preserving split of range(n): the first n % world ranks get one item more */
+void sfmx_shard_range(int n, int rank, int world, int* lo, int* hi);
+/* all-reduce of a small host array through the context's stream; op 0 = sum, 1 = max */
+int sfmx_comm_allreduce_f64(sfmx_ctx* ctx, sfmx_comm* comm, double* host_inout, int n, int op);
+int sfmx_comm_allreduce_u64_max(sfmx_ctx* ctx, sfmx_comm* comm, uint64_t* host_inout, int n);
+/* Point-sharded BA iteration (T:893-1095): prob holds THIS rank's contiguous range of the window's points (reference
+ * order); raw S | b of the shard -> one all-reduce(sum) of D*D + D doubles in HBM -> damping + gauge (T:1064-1071) ->
+ * solve on the device -> dx (identical on every rank).  The rank-ordered sum rounds differently from the sequential
+ * reference: this mode is held to 1e-9 relative agreement with the single-GPU step, not to bit-exactness; with
+ * world == 1 it equals sfmx_ba_step bit for bit. */
+int sfmx_ba_step_sharded(sfmx_ctx* ctx, sfmx_comm* comm, sfmx_ba_problem* prob, const double* poses_wc, double fx,
+                         double fy, double cx, double cy, double huber, double lambda, double* dx_out);
+
 /* ---- dense solve: replaces sfm::solve_gauss (cpp/include/dense.hpp:54-93) -------------------- */
 /* Gaussian elimination with partial pivoting in the reference's operation order; A [n][n]
  * row-major and b [n] are not modified; x [n].  SFMX_ERR_SINGULAR when a pivot is < 1e-15. */

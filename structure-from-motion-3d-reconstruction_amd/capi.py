@@ -26,7 +26,9 @@ SYMBOLS = [
     "sfmx_last_kernel_us", "sfmx_kernel_profile", "sfmx_kernel_profile_name", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
     "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_ransac_score_ex", "sfmx_sampson_mask", "sfmx_ba_create",
-    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_solve_dense",
+    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_ba_step_sharded", "sfmx_solve_dense",
+    "sfmx_comm_get_unique_id", "sfmx_comm_create", "sfmx_comm_destroy", "sfmx_comm_rank", "sfmx_comm_world", "sfmx_shard_range",
+    "sfmx_comm_allreduce_f64", "sfmx_comm_allreduce_u64_max",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt", "sfmx_debug_klt_slow_steps",
 ]
 
@@ -140,6 +142,16 @@ class BaProblem:
             self.ctx._chk(rc)
         return rc, dx
 
+    def step_sharded(self, comm, poses_wc, fx, fy, cx, cy, huber, lam):
+        """point-sharded iteration: partial build, RCCL all-reduce of S|b in HBM, damping + gauge, solve (comm None = 1 rank)"""
+        poses = _f64(poses_wc)
+        dx = np.zeros(6 * self.W)
+        rc = self.ctx.lib.sfmx_ba_step_sharded(self.ctx.h_, comm.h_ if comm is not None else None, self.h_, _p(poses, c_double), c_double(fx),
+                                               c_double(fy), c_double(cx), c_double(cy), c_double(huber), c_double(lam), _p(dx, c_double))
+        if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
+            self.ctx._chk(rc)
+        return rc, dx
+
     def build_partial(self, poses_wc, fx, fy, cx, cy, huber):
         """device pointers (S, b) of this shard's raw sums — for RCCL all-reduce by the caller"""
         poses = _f64(poses_wc)
@@ -158,6 +170,47 @@ class BaProblem:
             self.close()
         except Exception:
             pass
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """rank 0: the 128-byte RCCL unique id the other ranks need for Comm(...)"""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    rc = load_library().sfmx_comm_get_unique_id(buf)
+    if rc != SFMX_OK:
+        raise SfmxError(rc, "sfmx_comm_get_unique_id (is librccl loadable?)")
+    return buf.raw
+
+
+class Comm:
+    """One RCCL communicator (one per host thread / lane that issues collectives)."""
+
+    def __init__(self, device: int, unique_id: bytes | None, rank: int, world: int):
+        self.lib = load_library()
+        self.h_ = c_void_p()
+        rc = self.lib.sfmx_comm_create(c_int(device), unique_id, c_int(rank), c_int(world), byref(self.h_))
+        if rc != SFMX_OK:
+            raise SfmxError(rc, "sfmx_comm_create")
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self.h_:
+            self.lib.sfmx_comm_destroy(self.h_)
+            self.h_ = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_range(n: int, rank: int, world: int):
+    lo, hi = c_int(), c_int()
+    load_library().sfmx_shard_range(c_int(n), c_int(rank), c_int(world), byref(lo), byref(hi))
+    return lo.value, hi.value
 
 
 class Context:

@@ -889,6 +889,15 @@ static int launch_solve_kernels(sfmx_ctx* c, const double* dA, const double* db,
   return SFMX_OK;
 }
 
+// T:1064-1071 on a reduced system that was summed without it: S_ii += lambda, then the gauge on DoF 0..5
+__global__ void k_ba_damp_gauge(double* __restrict__ S, double* __restrict__ b, int D, double lambda) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D) return;
+  double v = S[(size_t)i * D + i] + lambda;
+  if (i < 6) { v = v + 1e9; b[i] = 0.0; }
+  S[(size_t)i * D + i] = v;
+}
+
 static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
                            double huber, double lambda, int damp, KernelTimer& t) {
   SFMX_HIP(c, c->h[0].ensure((size_t)q->W * 96));
@@ -924,7 +933,7 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
   const size_t o_x = 0, o_uv = up16((size_t)P * 24), o_ptr = o_uv + up16((size_t)R * 16), o_li = o_ptr + up16((size_t)(P + 1) * 4);
   const size_t in_bytes = o_li + up16((size_t)R * 4) + 16;
   const size_t need[11] = {in_bytes, 16, 16, 16, (size_t)W * 96,
-                           (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8, (size_t)D * 8, (size_t)D * 8 + 64,
+                           (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8 + (size_t)D * 8, 16, (size_t)D * 8 + 64,
                            (size_t)P * CS * 8};
   for (int i = 0; i < 11; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
   q->contrib = q->bufs[10].as<double>();
@@ -932,7 +941,7 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
   q->X = reinterpret_cast<double*>(in + o_x); q->obs_uv = reinterpret_cast<double*>(in + o_uv);
   q->obs_ptr = reinterpret_cast<int32_t*>(in + o_ptr); q->obs_li = reinterpret_cast<int32_t*>(in + o_li);
   q->poses = q->bufs[4].as<double>(); q->rec = q->bufs[5].as<double>();
-  q->slot_of = q->bufs[6].as<int8_t>(); q->S = q->bufs[7].as<double>(); q->b = q->bufs[8].as<double>();
+  q->slot_of = q->bufs[6].as<int8_t>(); q->S = q->bufs[7].as<double>(); q->b = q->S + (size_t)D * D;  // S | b contiguous: one all-reduce
   q->work = q->bufs[9].as<double>();
   if (c->ba_upload_in_flight) {  // two resets in a row: the staging slab is still being read
     SFMX_HIP(c, hipStreamSynchronize(c->stream));
@@ -1007,6 +1016,30 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
   KernelTimer t(c);
   int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t);
   if (rc) return rc;
+  int* dstatus = reinterpret_cast<int*>(q->work + D);
+  rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
+  if (rc) return rc;
+  int status = 0;
+  SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 8));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, q->work, (size_t)D * 8 + 4, hipMemcpyDeviceToHost, c->stream));  // dx | status
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  c->ba_upload_in_flight = false;
+  t.collect();
+  memcpy(dx_out, c->h[1].p, (size_t)D * 8);
+  memcpy(&status, c->h[1].as<char>() + (size_t)D * 8, 4);
+  return status ? SFMX_ERR_SINGULAR : SFMX_OK;
+}
+
+int sfmx_ba_step_sharded(sfmx_ctx* c, sfmx_comm* comm, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
+                         double huber, double lambda, double* dx_out) {
+  SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
+  const int D = 6 * q->W;
+  KernelTimer t(c);
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, 0.0, 0, t);  // raw sums of this rank's points
+  if (rc) return rc;
+  rc = sfmx_comm_allreduce_dev(c, comm, q->S, (size_t)D * D + D, 0, 0);        // S | b, in HBM, on the BA stream
+  if (rc) return rc;
+  k_ba_damp_gauge<<<(D + 63) / 64, 64, 0, c->stream>>>(q->S, q->b, D, lambda);
   int* dstatus = reinterpret_cast<int*>(q->work + D);
   rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
   if (rc) return rc;

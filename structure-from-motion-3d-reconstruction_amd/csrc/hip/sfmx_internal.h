@@ -88,6 +88,13 @@ struct sfmx_ctx {
   int wl_md = 0, wl_ntaps = 0;
 };
 
+struct sfmx_comm {
+  void* nccl = nullptr;  // ncclComm_t; null when world == 1
+  int rank = 0, world = 1, device = 0;
+};
+// comm.hip: in-place all-reduce of device memory on the context's stream (dtype 0 = f64, 1 = u64; op 0 = sum, 1 = max)
+int sfmx_comm_allreduce_dev(sfmx_ctx* ctx, sfmx_comm* comm, void* dev, size_t count, int dtype, int op);
+
 struct sfmx_pyramid {
   int w = 0, h = 0, levels = 0;
   uint8_t* base = nullptr;

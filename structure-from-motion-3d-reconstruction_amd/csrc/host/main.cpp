@@ -3,6 +3,7 @@
 // CSV / PLY outputs and exit codes (2 usage, 0 ok/help, 1 "ERROR: ...").
 //
 // --export-geometry mesh|both writes templeRing_mesh_sparse_kf<k>.ply through mesh.cpp (T:1884-1906).
+#include <chrono>
 #include <cstdlib>
 #include <filesystem>
 #include <fstream>
@@ -10,6 +11,7 @@
 #include <sstream>
 #include <optional>
 #include <string>
+#include <thread>
 
 #include "cli_io.hpp"
 #include "pipeline.hpp"
@@ -238,14 +240,51 @@ int main(int argc, char** argv) {
       src.h = g0.h;
     }
 
-    sfmx_ctx* ctx = nullptr;
+    // Multi-GPU mode (not part of the reference's command line, so it lives in the environment): SFMX_DIST_WORLD=N processes,
+    // one per GPU, each started with its SFMX_DIST_RANK and a common SFMX_DIST_ID_FILE, run the SAME sequence and shard BA
+    // points and RANSAC hypotheses.  Rank 0 writes the RCCL unique ids into the file, prints and writes outputs.
+    const int dist_world = std::getenv("SFMX_DIST_WORLD") ? std::atoi(std::getenv("SFMX_DIST_WORLD")) : 1;
+    const int dist_rank = std::getenv("SFMX_DIST_RANK") ? std::atoi(std::getenv("SFMX_DIST_RANK")) : 0;
     const char* dev_env = std::getenv("SFMX_DEVICE");
-    const int rc = sfmx_ctx_create(dev_env ? std::atoi(dev_env) : 0, &ctx);
+    const int device = dev_env ? std::atoi(dev_env) : (dist_world > 1 ? dist_rank : 0);
+    sfmx_ctx* ctx = nullptr;
+    const int rc = sfmx_ctx_create(device, &ctx);
     if (rc != SFMX_OK) throw std::runtime_error("no usable MI355X (gfx950) device: sfmx_ctx_create failed (there is no CPU fallback)");
     struct CtxGuard { sfmx_ctx* c; ~CtxGuard() { sfmx_ctx_destroy(c); } } guard{ctx};
+    struct Comms {
+      sfmx_comm* c[3] = {nullptr, nullptr, nullptr};
+      ~Comms() { for (sfmx_comm* m : c) sfmx_comm_destroy(m); }
+    } comms;
+    if (dist_world > 1) {
+      const char* idf = std::getenv("SFMX_DIST_ID_FILE");
+      if (!idf || dist_rank < 0 || dist_rank >= dist_world) throw std::runtime_error("SFMX_DIST_WORLD needs SFMX_DIST_RANK in range and SFMX_DIST_ID_FILE");
+      std::string ids((size_t)3 * SFMX_COMM_ID_BYTES, '\0');
+      if (dist_rank == 0) {
+        for (int k = 0; k < 3; k++)
+          if (sfmx_comm_get_unique_id(&ids[(size_t)k * SFMX_COMM_ID_BYTES]) != SFMX_OK) throw std::runtime_error("RCCL is not available (sfmx_comm_get_unique_id)");
+        const std::string tmp = std::string(idf) + ".tmp";
+        { std::ofstream f(tmp, std::ios::binary); f.write(ids.data(), (std::streamsize)ids.size()); }
+        fs::rename(tmp, idf);
+      } else {
+        for (int tries = 0;; ++tries) {  // wait for rank 0 (up to two minutes)
+          std::ifstream f(idf, std::ios::binary);
+          if (f && f.read(&ids[0], (std::streamsize)ids.size())) break;
+          if (tries > 1200) throw std::runtime_error(std::string("timed out waiting for ") + idf);
+          std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+      }
+      for (int k = 0; k < 3; k++)
+        if (sfmx_comm_create(device, &ids[(size_t)k * SFMX_COMM_ID_BYTES], dist_rank, dist_world, &comms.c[k]) != SFMX_OK)
+          throw std::runtime_error("sfmx_comm_create failed (RCCL)");
+      pc.comm_ba = comms.c[0];
+      pc.comm_ransac_a = comms.c[1];
+      pc.comm_ransac_c = comms.c[2];
+    }
+    const bool speaker = dist_rank == 0;  // every rank computes the same result; one of them reports it
 
     PipelineResult res;
-    run_pipeline(ctx, src, meta, K, pc, res, echo_line);
+    run_pipeline(ctx, src, meta, K, pc, res, speaker ? echo_line : nullptr);
+    if (!speaker) return 0;
     const size_t printed = res.log.size();
     write_outputs(out.string(), pc, meta, res);
     if (want_mesh) {  // T:1884-1906

@@ -622,7 +622,7 @@ StepOut GpuTracker::step(FrameSource& src, int fi) {
 
 // ------------------------------------------------------------------------------------------ RANSAC
 std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
-                                         double thr, int min_inliers, StageClock* clk) {
+                                         double thr, int min_inliers, StageClock* clk, sfmx_comm* comm) {
   if (pi.size() < 8) return std::nullopt;  // T:648
   const auto t0 = Clock::now();
   Mat3 Kinv;
@@ -668,11 +668,18 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
   if (iters <= 0) return std::nullopt;
   if (clk) clk->r_pre += since(t0);
   const auto tg0 = Clock::now();
-  std::vector<std::int32_t> counts((size_t)iters), lo((size_t)iters), hi((size_t)iters);
+  // hypothesis sharding: this rank scores iterations [h0, h1) of the common sample stream; everything below works on the
+  // local range with GLOBAL iteration numbers and is merged with three tiny collectives (one rank: h0 = 0, h1 = iters)
+  int h0 = 0, h1 = iters;
+  const bool sharded = comm && sfmx_comm_world(comm) > 1;
+  if (sharded) sfmx_shard_range(iters, sfmx_comm_rank(comm), sfmx_comm_world(comm), &h0, &h1);
+  const int hl = h1 - h0;
+  std::vector<std::int32_t> counts((size_t)iters, 0), lo((size_t)iters, 0), hi((size_t)iters, 0);
   std::int32_t best_iter = -1, best_count = 0;
-  check(ctx, sfmx_ransac_score_ex(ctx, xi.data(), xj.data(), n, idx8.data(), iters, thr, counts.data(), lo.data(), hi.data(), nullptr, nullptr,
-                                  &best_iter, &best_count, nullptr),
-        "ransac_score");
+  if (hl > 0)
+    check(ctx, sfmx_ransac_score_ex(ctx, xi.data(), xj.data(), n, idx8.data() + (size_t)8 * h0, hl, thr, counts.data() + h0, lo.data() + h0,
+                                    hi.data() + h0, nullptr, nullptr, &best_iter, &best_count, nullptr),
+          "ransac_score");
   if (clk) {
     clk->ransac_kernel_us += sfmx_last_kernel_us(ctx);
     clk->ransac_calls++;
@@ -688,7 +695,13 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
   // E and mask are what leaves this function.
   std::optional<RelPose> result;
   int best_lo = 0, best_hi = 0;
-  for (int it = 0; it < iters; ++it) { best_lo = std::max(best_lo, lo[(size_t)it]); best_hi = std::max(best_hi, hi[(size_t)it]); }
+  for (int it = h0; it < h1; ++it) { best_lo = std::max(best_lo, lo[(size_t)it]); best_hi = std::max(best_hi, hi[(size_t)it]); }
+  if (sharded) {  // the bounds every rank prunes with are the global ones
+    double b2[2] = {(double)best_lo, (double)best_hi};
+    check(ctx, sfmx_comm_allreduce_f64(ctx, comm, b2, 2, 1), "allreduce(max) of the count bounds");
+    best_lo = (int)b2[0];
+    best_hi = (int)b2[1];
+  }
   if (best_hi > 0 && best_hi >= min_inliers) {
     int win_iter = -1, win_count = -1;
     Mat3 winE;
@@ -708,12 +721,12 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
     };
     // pass 1: exact counts of the uncertain candidates; the best certain candidate (count, lowest iteration)
     int cert_iter = -1, cert_count = -1;
-    for (int it = 0; it < iters; ++it) {
+    for (int it = h0; it < h1; ++it) {
       if (hi[(size_t)it] < best_lo || hi[(size_t)it] <= 0) continue;
       if (lo[(size_t)it] < hi[(size_t)it]) verify(it);
       else if (counts[(size_t)it] > cert_count) { cert_count = counts[(size_t)it]; cert_iter = it; }
     }
-    // pass 2: the best certain candidate beats (or ties earlier than) every verified one?  Then it is the winner and
+    // pass 2: the best certain candidate beats (or ties earlier than) every verified one?  Then it is this rank's winner and
     // needs its exact E and mask; its exact count must equal the certified one.
     if (cert_iter >= 0 && (cert_count > win_count || (cert_count == win_count && cert_iter < win_iter))) {
       const int cnt = verify(cert_iter);
@@ -721,8 +734,27 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
         // A certificate did not hold (never observed).  Parity first: fall back to exact counts of every candidate.
         if (clk) clk->ransac_cert_misses++;
         win_iter = -1; win_count = -1;
-        for (int it = 0; it < iters; ++it)
+        for (int it = h0; it < h1; ++it)
           if (hi[(size_t)it] >= best_lo - 4 && hi[(size_t)it] > 0) verify(it);
+      }
+    }
+    if (sharded) {
+      // global winner: max count, lowest iteration (T:673) over the ranks' exact local winners; its E travels as raw bits
+      // (max over {bits, 0, 0, ...}: exact, signs of zeros included), its mask is recomputed from that E by every rank
+      std::uint64_t key = win_iter >= 0 ? (((std::uint64_t)(std::uint32_t)win_count << 32) | (std::uint64_t)(0x7fffffff - win_iter)) : 0;
+      const std::uint64_t mine = key;
+      check(ctx, sfmx_comm_allreduce_u64_max(ctx, comm, &key, 1), "allreduce(max) of the winner key");
+      std::uint64_t ebits[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (key != 0 && key == mine) std::memcpy(ebits, winE.a, 72);
+      check(ctx, sfmx_comm_allreduce_u64_max(ctx, comm, ebits, 9), "allreduce of the winner's E");
+      if (key == 0) { win_iter = -1; win_count = -1; }
+      else if (key != mine) {
+        win_count = (int)(key >> 32);
+        win_iter = 0x7fffffff - (int)(key & 0xffffffffull);
+        std::memcpy(winE.a, ebits, 72);
+        std::int32_t cnt = 0;
+        check(ctx, sfmx_sampson_mask(ctx, xi.data(), xj.data(), n, winE.a, thr, mask.data(), &cnt), "sampson_mask");
+        win_mask = mask;
       }
     }
     if (clk) clk->r_verify += since(tv0);
@@ -814,8 +846,29 @@ void GpuBundleAdjuster::solve(BaJob& job) {
   const auto t0 = Clock::now();
   const int W = job.W, P = job.P, D = 6 * W;
   const Mat3& K = job.K;
-  if (!prob_) check(ctx_, sfmx_ba_create(ctx_, W, P, job.X.data(), job.optr.data(), job.oli.data(), job.uv.data(), &prob_), "ba_create");
-  else check(ctx_, sfmx_ba_reset(ctx_, prob_, W, P, job.X.data(), job.optr.data(), job.oli.data(), job.uv.data()), "ba_reset");
+  // Point sharding: this rank keeps the contiguous range [lo, hi) of the window's points (reference order) and its
+  // observation lists; with fewer points than ranks every rank runs the whole (tiny) problem itself, no collective.
+  const bool sharded = comm_ && sfmx_comm_world(comm_) > 1 && P >= sfmx_comm_world(comm_);
+  const double* Xp = job.X.data();
+  const std::int32_t* optr = job.optr.data();
+  const std::int32_t* oli = job.oli.data();
+  const double* ouv = job.uv.data();
+  int Pl = P;
+  std::vector<std::int32_t> optr_local;
+  if (sharded) {
+    int lo = 0, hi = P;
+    sfmx_shard_range(P, sfmx_comm_rank(comm_), sfmx_comm_world(comm_), &lo, &hi);
+    Pl = hi - lo;
+    const std::int32_t o0 = job.optr[(size_t)lo];
+    optr_local.resize((size_t)Pl + 1);
+    for (int p = 0; p <= Pl; p++) optr_local[(size_t)p] = job.optr[(size_t)(lo + p)] - o0;
+    Xp += (size_t)3 * lo;
+    optr = optr_local.data();
+    oli += o0;
+    ouv += (size_t)2 * o0;
+  }
+  if (!prob_) check(ctx_, sfmx_ba_create(ctx_, W, Pl, Xp, optr, oli, ouv, &prob_), "ba_create");
+  else check(ctx_, sfmx_ba_reset(ctx_, prob_, W, Pl, Xp, optr, oli, ouv), "ba_reset");
   std::vector<double> poses((size_t)W * 12), dx((size_t)D);
   if (clk_) clk_->ba_calls++;
   for (int it = 0; it < job.cfg.iters; ++it) {
@@ -826,7 +879,9 @@ void GpuBundleAdjuster::solve(BaJob& job) {
       std::memcpy(&poses[(size_t)12 * li], R.a, 72);
       poses[(size_t)12 * li + 9] = t.x; poses[(size_t)12 * li + 10] = t.y; poses[(size_t)12 * li + 11] = t.z;
     }
-    const int rc = sfmx_ba_step(ctx_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), job.cfg.huber_delta, job.cfg.lambda, dx.data());
+    const int rc = sharded ? sfmx_ba_step_sharded(ctx_, comm_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), job.cfg.huber_delta,
+                                                  job.cfg.lambda, dx.data())
+                           : sfmx_ba_step(ctx_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), job.cfg.huber_delta, job.cfg.lambda, dx.data());
     if (clk_) { clk_->ba_kernel_us += sfmx_last_kernel_us(ctx_); clk_->ba_iters++; }
     if (rc == SFMX_ERR_SINGULAR) break;  // T:1076-1078: ill-conditioned -> skip the rest of BA
     check(ctx_, rc, "ba_step");
@@ -1171,7 +1226,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   if (lane_a && sfmx_get_timing(ctx)) (void)sfmx_set_timing(lane_a->ctx(), 1);
   std::function<void(FramePacket&)> on_packet;
   if (lane_a)
-    on_packet = [&lane_a, &lane_a_clk, K](FramePacket& p) {
+    on_packet = [&lane_a, &lane_a_clk, K, comm_a = cfg.comm_ransac_a](FramePacket& p) {
       if (p.step.prev_pts.empty()) return;
       auto prom = std::make_shared<std::promise<std::optional<RelPose>>>();
       p.rel = prom->get_future().share();
@@ -1179,9 +1234,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       auto pj = std::make_shared<const std::vector<V2>>(p.step.cur_pts);
       AsyncLane* la = lane_a.get();
       StageClock* ck = &lane_a_clk;
-      la->submit([prom, pi, pj, la, ck, K]() {
+      la->submit([prom, pi, pj, la, ck, K, comm_a]() {
         try {
-          prom->set_value(find_E_ransac_gpu(la->ctx(), K, *pi, *pj, 2500, 1e-3, 60, ck));
+          prom->set_value(find_E_ransac_gpu(la->ctx(), K, *pi, *pj, 2500, 1e-3, 60, ck, comm_a));
         } catch (...) {
           prom->set_exception(std::current_exception());
         }
@@ -1220,7 +1275,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   StageClock* bclk = lane ? &lane_clk : &clk;
   sfmx_ctx* cctx = lane_c ? lane_c->ctx() : ctx;
   StageClock* cclk = lane_c ? &lane_c_clk : &clk;
-  GpuBundleAdjuster ba(bctx, bclk);
+  GpuBundleAdjuster ba(bctx, bclk, cfg.comm_ba);
   sfmx_pyramid* old_pyr_c = nullptr;  // lane C's copy of the old keyframe image
   struct PyrGuardC { sfmx_ctx* c; sfmx_pyramid** p; ~PyrGuardC() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard_c{cctx, &old_pyr_c};
   struct PendingEdge { int i, j; std::optional<RelPose> rel; };
@@ -1326,7 +1381,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     const auto tm1 = Clock::now();
     std::optional<RelPose> rel;
     if (pkt.rel.valid()) rel = pkt.rel.get();                                     // T:1739, started ahead on lane A
-    else rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk);
+    else rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk, cfg.comm_ransac_a);
     clk.m_ransac += since(tm1);
     int inliers = 0;
     double parallax = 0.0;
@@ -1382,8 +1437,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         if (ei.size() >= 80) {
           pending_edges.push_back(PendingEdge{prev_kf.kf_id, kf.kf_id, std::nullopt});
           PendingEdge* slot = &pending_edges.back();  // std::deque: stays valid while later edges are appended
-          auto task = [slot, cctx, cclk, K, ei = std::move(ei), ej = std::move(ej)]() {
-            slot->rel = find_E_ransac_gpu(cctx, K, ei, ej, 2500, 1e-3, 60, cclk);
+          auto task = [slot, cctx, cclk, K, comm_c = cfg.comm_ransac_c, ei = std::move(ei), ej = std::move(ej)]() {
+            slot->rel = find_E_ransac_gpu(cctx, K, ei, ej, 2500, 1e-3, 60, cclk, comm_c);
           };
           if (lane_c) lane_c->submit(std::move(task));
           else task();
@@ -1487,7 +1542,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
             li.push_back(pts0[i]);
             lj.push_back(fwd[i]);
           }
-          if (li.size() >= 120) pending_loop.rel = find_E_ransac_gpu(cctx, K, li, lj, 4000, 2e-3, 80, cclk);
+          if (li.size() >= 120) pending_loop.rel = find_E_ransac_gpu(cctx, K, li, lj, 4000, 2e-3, 80, cclk, cfg.comm_ransac_c);
         };
         if (lane_c) lane_c->submit(std::move(verify));
         else { verify(); join_lane(); }
@@ -1598,6 +1653,7 @@ struct sfmx_pipeline_cfg {
   double kf_parallax_px;
   int ba_window, ba_iters, ba_max_points;
   double ba_huber, ba_lambda;
+  sfmx_comm *comm_ba, *comm_ransac_a, *comm_ransac_c;  // multi-GPU mode (PipelineConfig); null = unsharded
 };
 struct sfmx_pipeline_stats {
   int n_keyframes, n_points, n_edges, n_frames;
@@ -1645,6 +1701,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     pc.kf_min_gap = cfg->kf_min_gap; pc.kf_min_inliers = cfg->kf_min_inliers; pc.kf_parallax_px = cfg->kf_parallax_px;
     pc.ba.window = cfg->ba_window; pc.ba.iters = cfg->ba_iters; pc.ba.max_points = cfg->ba_max_points;
     pc.ba.huber_delta = cfg->ba_huber; pc.ba.lambda = cfg->ba_lambda;
+    pc.comm_ba = cfg->comm_ba; pc.comm_ransac_a = cfg->comm_ransac_a; pc.comm_ransac_c = cfg->comm_ransac_c;
     PipelineResult res;
     run_pipeline(ctx, src, meta, K, pc, res);  // returns after its lanes / prefetch contexts are torn down
     const double wall = since(t_wall);

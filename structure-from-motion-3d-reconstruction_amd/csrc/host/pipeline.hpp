@@ -322,8 +322,10 @@ void klt_pairs(sfmx_ctx* ctx, const LKConfig& cfg, const sfmx_pyramid* a, const 
                std::vector<std::uint8_t>& keep, StageClock* clk);
 
 // find_E_ransac (T:646-761); throws std::runtime_error("Singular K") like the reference
+// comm (optional): the iterations are sharded over its ranks; counts are exact per iteration, so every rank returns the
+// single-GPU result bit for bit (all-reduce(max) of the packed (count, iteration) key, winner's E carried as raw bits)
 std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
-                                         double thr, int min_inliers, StageClock* clk);
+                                         double thr, int min_inliers, StageClock* clk, sfmx_comm* comm = nullptr);
 
 // T:766-798
 struct Keyframe {
@@ -374,7 +376,8 @@ struct BaJob {
 };
 class GpuBundleAdjuster {
  public:
-  GpuBundleAdjuster(sfmx_ctx* ctx, StageClock* clk) : ctx_(ctx), clk_(clk) {}
+  // comm (optional): the window's points are sharded over its ranks, S | b all-reduced per iteration (sfmx_ba_step_sharded)
+  GpuBundleAdjuster(sfmx_ctx* ctx, StageClock* clk, sfmx_comm* comm = nullptr) : ctx_(ctx), clk_(clk), comm_(comm) {}
   ~GpuBundleAdjuster();
   static BaJob gather(const Mat3& K, const std::vector<Keyframe>& kfs, const MapState& map, const BAConfig& cfg);
   void solve(BaJob& job);
@@ -388,6 +391,7 @@ class GpuBundleAdjuster {
  private:
   sfmx_ctx* ctx_;
   StageClock* clk_;
+  sfmx_comm* comm_ = nullptr;
   sfmx_ba_problem* prob_ = nullptr;
 };
 
@@ -432,6 +436,12 @@ struct PipelineConfig {
   BAConfig ba;
   int kf_min_gap = 1, kf_min_inliers = 200;
   double kf_parallax_px = 18.0;
+  // Multi-GPU mode (one process per GPU, every rank runs the same sequence): BA points and RANSAC hypotheses are
+  // sharded over the ranks of these communicators.  One communicator per lane that issues collectives:
+  // BA (lane B), frame->frame RANSAC (lane A) and keyframe->keyframe / loop-closure RANSAC (lane C).  null = unsharded.
+  sfmx_comm* comm_ba = nullptr;
+  sfmx_comm* comm_ransac_a = nullptr;
+  sfmx_comm* comm_ransac_c = nullptr;
 };
 struct FrameMeta {
   std::string name;

@@ -10,7 +10,12 @@ Units that shard:
                                   is the reference's strict '>' (T:673)
 The reductions are tiny, so they are issued as single collectives (no bucketing); rank-ordered summation of the BA
 partials rounds differently from the sequential reference, hence this mode is held to 1e-9 relative agreement
-(single-GPU ordered mode stays the bit-exact parity reference).
+(single-GPU ordered mode stays the bit-exact parity reference).  Hypothesis sharding is exact: counts are integers.
+
+The product path is native: libsfmx issues the collectives itself (csrc/hip/comm.hip: sfmx_comm_*, sfmx_ba_step_sharded;
+csrc/host/pipeline.cpp: find_E_ransac_gpu / GpuBundleAdjuster with a communicator).  The functions below that take
+torch tensors are the same index arithmetic and reductions in torch form; tests/test_dist_cpu.py runs them over gloo
+with world size 2 (no GPU needed), make_comms() / ba_step_sharded() are the glue to the native path.
 """
 from __future__ import annotations
 
@@ -74,21 +79,25 @@ def allreduce_best_hypothesis(count: int, iteration: int, device="cpu", group=No
     return unpack_best(int(t.item()))
 
 
-class _DevArray:
-    """Expose a raw HBM pointer (sfmx_ba_build_partial) to torch without a copy."""
+def make_comms(count: int, device_index: int, group=None):
+    """`count` native RCCL communicators (capi.Comm) over the ranks of an initialised torch.distributed group: rank 0
+    creates the unique ids, torch.distributed carries them (the only thing torch does on this path; the collectives of
+    the data path are issued by libsfmx itself, in HBM, on its own streams).  World size 1 needs no RCCL at all."""
+    from . import capi
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    comms = []
+    for _ in range(count):
+        uid = None
+        if world > 1:
+            box = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = box[0]
+        comms.append(capi.Comm(device_index, uid, rank, world))
+    return comms
 
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
-
-def ba_step_sharded(ctx, prob, poses_wc, fx, fy, cx, cy, huber, lam, device, group=None):
-    """One BA iteration with this rank's point shard resident in `prob`: partial build on the GPU, RCCL all-reduce of
-    (S,b) in HBM, damping + gauge, dense solve through the C ABI.  Returns (status, dx)."""
-    D = 6 * prob.W
-    s_ptr, b_ptr = prob.build_partial(poses_wc, fx, fy, cx, cy, huber)
-    S = torch.as_tensor(_DevArray(s_ptr, D * D), device=device).reshape(D, D)
-    b = torch.as_tensor(_DevArray(b_ptr, D), device=device)
-    allreduce_normal_equations(S, b, group)
-    damp_and_gauge(S, b, lam)
-    torch.cuda.synchronize(device)
-    return ctx.solve_dense(S.cpu().numpy(), b.cpu().numpy())
+def ba_step_sharded(ctx, prob, poses_wc, fx, fy, cx, cy, huber, lam, comm=None):
+    """One BA iteration with this rank's point shard resident in `prob` (native path: partial build, RCCL all-reduce of
+    S | b in HBM on the context's stream, damping + gauge and the dense solve on the device).  Returns (status, dx)."""
+    return prob.step_sharded(comm, poses_wc, fx, fy, cx, cy, huber, lam)

@@ -18,7 +18,8 @@ class PipelineCfg(ctypes.Structure):
                 ("quality", c_double), ("min_distance", c_int), ("pyr_levels", c_int), ("win_radius", c_int),
                 ("klt_iters", c_int), ("fb_thresh", c_double), ("kf_min_gap", c_int), ("kf_min_inliers", c_int),
                 ("kf_parallax_px", c_double), ("ba_window", c_int), ("ba_iters", c_int), ("ba_max_points", c_int),
-                ("ba_huber", c_double), ("ba_lambda", c_double)]
+                ("ba_huber", c_double), ("ba_lambda", c_double),
+                ("comm_ba", c_void_p), ("comm_ransac_a", c_void_p), ("comm_ransac_c", c_void_p)]
 
 
 class PipelineStats(ctypes.Structure):
@@ -69,8 +70,10 @@ def load_host_library() -> ctypes.CDLL:
 
 
 def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=None, cfg: dict | None = None,
-        out_dir: str | None = None, images_dev: int | None = None, shape=None, timing: bool = False):
-    """Run the per-frame loop.  images: host [F,h,w] u8, or images_dev: device pointer with shape=(F,h,w)."""
+        out_dir: str | None = None, images_dev: int | None = None, shape=None, timing: bool = False, comms=None):
+    """Run the per-frame loop.  images: host [F,h,w] u8, or images_dev: device pointer with shape=(F,h,w).
+    comms (optional): (ba, ransac_a, ransac_c) capi.Comm objects -- every rank runs the same sequence, BA points and
+    RANSAC hypotheses are sharded over the ranks."""
     lib = load_host_library()
     if images is not None:
         images = np.ascontiguousarray(images, np.uint8)
@@ -78,6 +81,8 @@ def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=No
     else:
         F, h, w = shape
     c = PipelineCfg(**{**DEFAULTS, **(cfg or {})})
+    if comms is not None:
+        c.comm_ba, c.comm_ransac_a, c.comm_ransac_c = (m.h_ if m is not None else None for m in comms)
     arr = (c_char_p * F)(*[str(n).encode() for n in names])
     K = np.ascontiguousarray(K, np.float64).reshape(9)
     lat = np.zeros(F) if lat is None else np.ascontiguousarray(lat, np.float64)

@@ -95,3 +95,12 @@ def test_two_rank_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_native_shard_range_equals_python():
+    """sfmx_shard_range (libsfmx: what the native sharded BA / RANSAC use) == dist.shard_range (what the gloo test covers)"""
+    capi = importlib.import_module(H.PKG_NAME + ".capi")
+    for n in (0, 1, 7, 600, 2500, 50001):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                assert capi.shard_range(n, rank, world) == D.shard_range(n, rank, world)

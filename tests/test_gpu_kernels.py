@@ -451,13 +451,8 @@ def test_solve_dense_blocked_sizes(ctx):
         H.assert_bits_equal(x, ex, "rank-deficient blocked", nan_equal=True)
 
 
-def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
-    """dist.ba_step_sharded (partial build -> [all-reduce] -> damp/gauge -> solve) on one rank must equal the fused
-    sfmx_ba_step bit for bit: same sums, no collective reordering with world size 1."""
-    import torch
-    dist_mod = importlib.import_module(H.PKG_NAME + ".dist")
-    rng = np.random.default_rng(8)
-    W, P = 4, 50
+def _c4_like_problem(W, P, seed):
+    rng = np.random.default_rng(seed)
     pw = np.zeros((W, 12))
     for k in range(W):
         R, t = synth.ring_pose(3.0 * k)
@@ -466,13 +461,61 @@ def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
     X = rng.normal(size=(P, 3)) * 0.05
     ptr = np.arange(0, (P + 1) * W, W, dtype=np.int32)
     li = np.tile(np.arange(W, dtype=np.int32), P)
-    uv = np.zeros((P * W, 2))
-    for p in range(P):
-        for k in range(W):
-            Xc = pw[k, :9].reshape(3, 3) @ X[p] + pw[k, 9:]
-            uv[p * W + k] = [K[0, 0] * Xc[0] / Xc[2] + K[0, 2] + rng.normal(), K[1, 1] * Xc[1] / Xc[2] + K[1, 2] + rng.normal()]
+    Xc = np.einsum("kij,pj->pki", pw[:, :9].reshape(W, 3, 3), X) + pw[None, :, 9:]
+    uv = np.stack([K[0, 0] * Xc[..., 0] / Xc[..., 2] + K[0, 2], K[1, 1] * Xc[..., 1] / Xc[..., 2] + K[1, 2]], -1)
+    uv = np.ascontiguousarray((uv + rng.normal(size=uv.shape)).reshape(P * W, 2))
+    return pw, K, X, ptr, li, uv
+
+
+def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
+    """sfmx_ba_step_sharded (partial build -> [all-reduce] -> damp/gauge kernel -> solve) with one rank must equal the fused
+    sfmx_ba_step bit for bit: same sums, no collective reordering with world size 1 -- with no communicator and with a
+    world-size-1 communicator object."""
+    dist_mod = importlib.import_module(H.PKG_NAME + ".dist")
+    W, P = 4, 50
+    pw, K, X, ptr, li, uv = _c4_like_problem(W, P, 8)
     prob = ctx.ba_problem(W, X, ptr, li, uv)
     rc1, dx1 = prob.step(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
-    rc2, dx2 = dist_mod.ba_step_sharded(ctx, prob, pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, torch.device("cuda:0"))
-    assert rc1 == rc2 == 0
-    H.assert_bits_equal(dx1, dx2, "sharded vs fused dx")
+    rc2, dx2 = dist_mod.ba_step_sharded(ctx, prob, pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, None)
+    comm1 = capi.Comm(0, None, 0, 1)
+    rc3, dx3 = dist_mod.ba_step_sharded(ctx, prob, pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, comm1)
+    assert rc1 == rc2 == rc3 == 0
+    H.assert_bits_equal(dx1, dx2, "sharded (no comm) vs fused dx")
+    H.assert_bits_equal(dx1, dx3, "sharded (world 1) vs fused dx")
+    comm1.close()
+    prob.close()
+
+
+def test_ba_point_shards_sum_to_the_fused_system(ctx):
+    """The arithmetic of the N-rank mode on one GPU: the raw S | b of the contiguous point ranges sfmx_shard_range hands to
+    ranks 0..N-1, summed in rank order (what the all-reduce does), must agree with the single-rank system to 1e-9
+    relative (not bit for bit: the addends are grouped differently) and give a dx that close."""
+    W, P = 10, 5000
+    pw, K, X, ptr, li, uv = _c4_like_problem(W, P, 9)
+    D = 6 * W
+    full = ctx.ba_problem(W, X, ptr, li, uv)
+    S_ref, b_ref = full.build(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, False)
+    rc, dx_ref = full.step(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    assert rc == 0
+    for world in (2, 8):
+        S, b = np.zeros((D, D)), np.zeros(D)
+        covered = 0
+        for rank in range(world):
+            lo, hi = capi.shard_range(P, rank, world)
+            assert lo == covered
+            covered = hi
+            o0, o1 = int(ptr[lo]), int(ptr[hi])
+            shard = ctx.ba_problem(W, X[lo:hi], ptr[lo:hi + 1] - o0, li[o0:o1], uv[o0:o1])
+            Sr, br = shard.build(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, False)
+            S += Sr
+            b += br
+            shard.close()
+        assert covered == P
+        assert np.allclose(S, S_ref, rtol=0, atol=1e-9 * np.abs(S_ref).max())
+        assert np.allclose(b, b_ref, rtol=0, atol=1e-9 * np.abs(b_ref).max())
+        S[np.arange(D), np.arange(D)] += 1e-3
+        S[np.arange(6), np.arange(6)] += 1e9
+        b[:6] = 0.0
+        rc, dx = ctx.solve_dense(S, b)
+        assert rc == 0 and np.allclose(dx, dx_ref, rtol=0, atol=1e-7 * np.abs(dx_ref).max())
+    full.close()
