@@ -206,6 +206,17 @@ int sfmx_solve_dense(sfmx_ctx* ctx, const double* A, const double* b, int n, dou
  * results are identical either way. */
 uint64_t sfmx_debug_klt_slow_steps(const sfmx_ctx* ctx);
 
+/* ---- pose-graph normal equations, structured (TOLERANCE mode): replaces the dense 3N x 3N solve of
+ * posegraph_optimize_centers (T:1131-1197 -> dense.hpp:54-93) for large keyframe counts ------------ */
+/* The system is H = L (x) I_3 with L the N x N weighted graph Laplacian plus the gauge term, so the three coordinates
+ * are solved together on L: blocked Cholesky with the trailing update on the FP64 matrix cores
+ * (v_mfma_f64_16x16x4_f64), then blocked triangular solves.  entry_ij [m][2] / entry_v [m]: the distinct entries of
+ * the LOWER triangle of L (row >= column), already summed; g3, x3 [n][3].  A different factorisation than the
+ * reference's elimination: agrees with solve_gauss on the dense system to ~1e-12 relative (tests: 1e-9), not bit for
+ * bit.  SFMX_ERR_SINGULAR where a pivot is not > 1e-15 (a keyframe not connected to node 0: the reference throws). */
+int sfmx_posegraph_solve(sfmx_ctx* ctx, int n, const int32_t* entry_ij, const double* entry_v, int m,
+                         const double* g3, double* x3);
+
 /* ---- self-check hooks used by the parity tests (device arithmetic vs the host libm) ---------- */
 int sfmx_debug_hypot(sfmx_ctx* ctx, const double* x, const double* y, int n, double* out);
 int sfmx_debug_divsqrt(sfmx_ctx* ctx, const double* x, const double* y, int n, double* div_out,

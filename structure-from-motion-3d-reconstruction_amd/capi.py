@@ -26,7 +26,7 @@ SYMBOLS = [
     "sfmx_last_kernel_us", "sfmx_kernel_profile", "sfmx_kernel_profile_name", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
     "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_ransac_score_ex", "sfmx_sampson_mask", "sfmx_ba_create",
-    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_ba_step_sharded", "sfmx_solve_dense",
+    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_ba_step_sharded", "sfmx_solve_dense", "sfmx_posegraph_solve",
     "sfmx_comm_get_unique_id", "sfmx_comm_create", "sfmx_comm_destroy", "sfmx_comm_rank", "sfmx_comm_world", "sfmx_shard_range",
     "sfmx_comm_allreduce_f64", "sfmx_comm_allreduce_u64_max",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt", "sfmx_debug_klt_slow_steps",
@@ -340,6 +340,17 @@ class Context:
         n = b.shape[0]
         x = np.zeros(n)
         rc = self.lib.sfmx_solve_dense(self.h_, _p(A, c_double), _p(b, c_double), c_int(n), _p(x, c_double))
+        if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
+            self._chk(rc)
+        return rc, x
+
+    def posegraph_solve(self, n, entries_ij, entries_v, g3):
+        """structured pose-graph solve (tolerance mode): lower-triangle entries of L, g [n][3] -> (status, x [n][3])"""
+        ij = np.ascontiguousarray(entries_ij, np.int32).reshape(-1, 2)
+        v = _f64(entries_v)
+        g = _f64(g3).reshape(n, 3)
+        x = np.zeros((n, 3))
+        rc = self.lib.sfmx_posegraph_solve(self.h_, c_int(n), _p(ij, c_int32), _p(v, c_double), c_int(len(v)), _p(g, c_double), _p(x, c_double))
         if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
             self._chk(rc)
         return rc, x

@@ -22,6 +22,7 @@
 // Algorithmic bytes per BA iteration: 20*R + 24*P + 96*W read, 8*(D^2+D) written.
 #include "sfmx_internal.h"
 
+#include <cstdlib>
 #include <mutex>
 
 #define BA_SLOT 84  // doubles per (point, pose) slot: Hxx 36 | bx 6 | Hxp 18 | G 18 | G*bp 6
@@ -797,9 +798,15 @@ __global__ __launch_bounds__(LU_TILE* LU_TILE) void k_lu_update(double* __restri
 // strictly serial and can only start when x[i+1] exists, so everything else is taken off that path: while thread 0
 // runs the chain of row i out of LDS, the other threads stage row i-1 -- the products A(i-1,j)*x[j] for the columns
 // whose x is known (x lives in LDS), the raw A(i-1,i) for the one that is not; thread 0 forms that last product itself.
-__global__ __launch_bounds__(512) void k_lu_backsub(const double* __restrict__ Wm, int n, double* __restrict__ x, int* __restrict__ status) {
-  extern __shared__ __align__(16) double bs_lds[];  // x[n] | row buffers [2][n]
+// IN_LDS = false (n > SOLVE_LDS_MAX_N: x and the two staged rows no longer fit in 156 KiB): the same schedule with the
+// three arrays in a global scratch buffer (same workgroup, so __syncthreads() orders the hand-over); slower per
+// element, still the reference's subtraction chain.
+template <bool IN_LDS>
+__global__ __launch_bounds__(512) void k_lu_backsub(const double* __restrict__ Wm, int n, double* __restrict__ x, int* __restrict__ status,
+                                                    double* __restrict__ gscratch) {
+  extern __shared__ __align__(16) double bs_dyn[];  // x[n] | row buffers [2][n]
   if (status[0]) return;
+  double* bs_lds = IN_LDS ? bs_dyn : gscratch;
   double* xs = bs_lds;
   const int ld = n + 1, tid = threadIdx.x, nt = blockDim.x;
   for (int i = n - 1; i >= 0; i--) {
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(512) void k_lu_backsub(const double* __restrict__ W
   }
 }
 
-#define SOLVE_MAX_N 6400  // back-substitution keeps x and two staged rows in LDS: 3 * n * 8 <= 156 KiB
+#define SOLVE_LDS_MAX_N 6400  // back-substitution keeps x and two staged rows in LDS while 3 * n * 8 <= 156 KiB
 
 // n == 36 / 60: rows in registers.  n <= 64: wave-synchronous LDS kernel.  Larger systems (pose graphs): blocked
 // elimination over the whole device on a working copy [n][n+1] in ctx->d[7].
@@ -853,7 +860,10 @@ static int launch_solve_kernels(sfmx_ctx* c, const double* dA, const double* db,
   } else {
     const size_t wbytes = (size_t)n * (n + 1) * 8, abytes = (size_t)n * 8, pbytes = (((size_t)n * 4) + 15) & ~(size_t)15;
     const size_t sbytes = (size_t)n * LU_NB * 8;  // column-major panel copy when it does not fit in LDS
-    SFMX_HIP(c, c->d[7].ensure(wbytes + abytes + pbytes + sbytes + 64));
+    const int lds_max_n = getenv("SFMX_BACKSUB_LDS_MAX_N") ? atoi(getenv("SFMX_BACKSUB_LDS_MAX_N")) : SOLVE_LDS_MAX_N;  // test hook
+    const bool bs_in_lds = n <= lds_max_n && n <= SOLVE_LDS_MAX_N;
+    const size_t gbytes = bs_in_lds ? 0 : (size_t)3 * n * 8;
+    SFMX_HIP(c, c->d[7].ensure(wbytes + abytes + pbytes + sbytes + gbytes + 64));
     double* Wm = c->d[7].as<double>();
     double* akk = reinterpret_cast<double*>(c->d[7].as<char>() + wbytes);
     int* piv = reinterpret_cast<int*>(c->d[7].as<char>() + wbytes + abytes);
@@ -866,7 +876,7 @@ static int launch_solve_kernels(sfmx_ctx* c, const double* dA, const double* db,
       const int dev = c->device & 63;
       if (!attr_set[dev]) {
         SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
-        SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
+        SFMX_HIP(c, hipFuncSetAttribute((const void*)k_lu_backsub<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPanelLds));
         attr_set[dev] = true;
       }
     }
@@ -883,7 +893,9 @@ static int launch_solve_kernels(sfmx_ctx* c, const double* dA, const double* db,
         k_lu_update<<<grid, LU_TILE * LU_TILE, 0, c->stream>>>(Wm, n, k0, dstatus);
       }
     }
-    k_lu_backsub<<<1, 512, (size_t)3 * n * 8, c->stream>>>(Wm, n, dx, dstatus);
+    if (bs_in_lds) k_lu_backsub<true><<<1, 512, (size_t)3 * n * 8, c->stream>>>(Wm, n, dx, dstatus, nullptr);
+    else k_lu_backsub<false><<<1, 512, 0, c->stream>>>(Wm, n, dx, dstatus,
+                                                       reinterpret_cast<double*>(c->d[7].as<char>() + wbytes + abytes + pbytes + sbytes));
   }
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;
@@ -1056,7 +1068,6 @@ int sfmx_ba_step_sharded(sfmx_ctx* c, sfmx_comm* comm, sfmx_ba_problem* q, const
 
 int sfmx_solve_dense(sfmx_ctx* c, const double* A, const double* b, int n, double* x) {
   SFMX_REQUIRE(c, c && A && b && x && n >= 1);
-  if (n > SOLVE_MAX_N) return sfmx_fail(c, SFMX_ERR_UNSUPPORTED, "sfmx_solve_dense: n > 6400", hipSuccess);
   const size_t nb = (size_t)n * n * 8;
   c->resident_points = 0;
   SFMX_HIP(c, c->d[0].ensure(nb));

@@ -965,13 +965,47 @@ void AsyncLane::run() {
   }
 }
 
-// T:1131-1197 (assembly on the host, solve through the C ABI)
+// T:1131-1197 (assembly on the host, solve through the C ABI).  Up to 3N = kPoseGraphDenseMax unknowns the reference's own
+// dense system goes through sfmx_solve_dense (its elimination order, bit-exact).  Beyond that -- the reference needs
+// (3N)^2 doubles and O((3N)^3) time there -- the same equations are solved in their structured form H = L (x) I_3 by
+// sfmx_posegraph_solve (tolerance mode, ~1e-12 relative to the dense solve).  SFMX_POSEGRAPH_SOLVER=dense|structured
+// forces one of them.
+static int posegraph_dense_max() {
+  if (const char* e = std::getenv("SFMX_POSEGRAPH_SOLVER")) {
+    if (std::string(e) == "dense") return 0x7fffffff;
+    if (std::string(e) == "structured") return 0;
+  }
+  return 6400;
+}
 bool posegraph_optimize_centers(sfmx_ctx* ctx, std::vector<Keyframe>& kfs, const std::vector<PGEdge>& edges) {
   const int N = (int)kfs.size();
   if (N < 2 || edges.empty()) return false;
   const int D = 3 * N;
-  std::vector<double> H((size_t)D * D, 0.0), g((size_t)D, 0.0), dc((size_t)D, 0.0);
-  auto addI = [&](int a, int b, double s) { for (int d = 0; d < 3; d++) H[(size_t)(3 * a + d) * D + (3 * b + d)] += s; };
+  const bool dense = D <= posegraph_dense_max();
+  std::vector<double> H, g((size_t)D, 0.0), dc((size_t)D, 0.0);
+  if (dense) H.assign((size_t)D * D, 0.0);
+  // structured form: the distinct lower-triangle entries of L in first-touch order, each summed in edge order (the order
+  // the reference's `+=` meets them), the three identical diagonal copies of the dense form folded into one
+  std::vector<std::int32_t> ent_ij;
+  std::vector<double> ent_v;
+  std::unordered_map<std::uint64_t, int> ent_of;
+  auto addL = [&](int a, int b, double s) {
+    if (dense) {
+      for (int d = 0; d < 3; d++) H[(size_t)(3 * a + d) * D + (3 * b + d)] += s;
+      return;
+    }
+    if (b > a) return;  // symmetric: the mirrored call carries the same value
+    const std::uint64_t key = ((std::uint64_t)(std::uint32_t)a << 32) | (std::uint32_t)b;
+    auto it = ent_of.find(key);
+    if (it == ent_of.end()) {
+      ent_of.emplace(key, (int)ent_v.size());
+      ent_ij.push_back(a);
+      ent_ij.push_back(b);
+      ent_v.push_back(s);
+    } else {
+      ent_v[(size_t)it->second] += s;
+    }
+  };
   for (const PGEdge& e : edges) {
     if (e.i < 0 || e.j < 0 || e.i >= N || e.j >= N) continue;
     const V3 Ci = kfs[(size_t)e.i].pose.t, Cj = kfs[(size_t)e.j].pose.t;
@@ -982,14 +1016,30 @@ bool posegraph_optimize_centers(sfmx_ctx* ctx, std::vector<Keyframe>& kfs, const
     const V3 dm = L * dir;
     const V3 r = (Cj - Ci) - dm;
     const double w = e.is_loop ? 2.0 : 1.0;
-    addI(e.i, e.i, w); addI(e.j, e.j, w); addI(e.i, e.j, -w); addI(e.j, e.i, -w);
+    addL(e.i, e.i, w); addL(e.j, e.j, w); addL(e.i, e.j, -w); addL(e.j, e.i, -w);
     g[(size_t)3 * e.i + 0] += w * (-r.x); g[(size_t)3 * e.i + 1] += w * (-r.y); g[(size_t)3 * e.i + 2] += w * (-r.z);
     g[(size_t)3 * e.j + 0] += w * (r.x);  g[(size_t)3 * e.j + 1] += w * (r.y);  g[(size_t)3 * e.j + 2] += w * (r.z);
   }
-  for (int d = 0; d < 3; d++) { H[(size_t)d * D + d] += 1e9; g[(size_t)d] = 0.0; }
-  const int rc = sfmx_solve_dense(ctx, H.data(), g.data(), D, dc.data());
+  if (dense) {
+    for (int d = 0; d < 3; d++) H[(size_t)d * D + d] += 1e9;
+  } else {
+    addL(0, 0, 1e9);
+  }
+  for (int d = 0; d < 3; d++) g[(size_t)d] = 0.0;
+  int rc;
+  if (dense) {
+    rc = sfmx_solve_dense(ctx, H.data(), g.data(), D, dc.data());
+  } else {
+    if (ent_v.empty()) return false;
+    // a node no edge touches has an all-zero row: the reference's elimination meets a zero pivot there and gives up
+    std::vector<char> touched((size_t)N, 0);
+    for (size_t k = 0; k < ent_v.size(); k++) touched[(size_t)ent_ij[2 * k]] = touched[(size_t)ent_ij[2 * k + 1]] = 1;
+    for (int i = 0; i < N; i++)
+      if (!touched[(size_t)i]) return false;
+    rc = sfmx_posegraph_solve(ctx, N, ent_ij.data(), ent_v.data(), (int)ent_v.size(), g.data(), dc.data());
+  }
   if (rc == SFMX_ERR_SINGULAR) return false;
-  check(ctx, rc, "solve_dense(pose graph)");
+  check(ctx, rc, "solve (pose graph)");
   for (int i = 1; i < N; i++) {
     kfs[(size_t)i].pose.t.x += dc[(size_t)3 * i];
     kfs[(size_t)i].pose.t.y += dc[(size_t)3 * i + 1];
@@ -1819,6 +1869,40 @@ int sfmx_host_tracker_tracks(void* h, double* xy, int* ids, int cap) {  // KLTTr
   if (n > cap) return -SFMX_ERR_INVALID;
   for (int i = 0; i < n; i++) { xy[2 * i] = tr[(size_t)i].p.x; xy[2 * i + 1] = tr[(size_t)i].p.y; ids[i] = tr[(size_t)i].id; }
   return n;
+}
+
+// posegraph_optimize_centers (T:1131-1197) on its own: R9s [n][9] camera->world rotations, centres [n][3] updated in
+// place, edges (i, j, R_ji [9], t_ji [3], is_loop).  1 = solved, 0 = skipped (singular / empty), < 0 = -status
+int sfmx_host_posegraph(sfmx_ctx* ctx, int n_kf, const double* R9s, double* centres3, int n_edges, const int* ei, const int* ej, const double* eR,
+                        const double* et, const int* is_loop) {
+  using namespace sfmx_host;
+  try {
+    Arena arena;
+    std::vector<Keyframe> kfs;
+    kfs.reserve((size_t)n_kf);
+    for (int k = 0; k < n_kf; k++) {
+      kfs.emplace_back(&arena);
+      kfs.back().kf_id = k;
+      std::memcpy(kfs.back().pose.R.a, R9s + 9 * k, 72);
+      kfs.back().pose.t = {centres3[3 * k], centres3[3 * k + 1], centres3[3 * k + 2]};
+    }
+    std::vector<PGEdge> edges((size_t)n_edges);
+    for (int e = 0; e < n_edges; e++) {
+      edges[(size_t)e].i = ei[e];
+      edges[(size_t)e].j = ej[e];
+      std::memcpy(edges[(size_t)e].R_ji.a, eR + 9 * e, 72);
+      edges[(size_t)e].t_ji = {et[3 * e], et[3 * e + 1], et[3 * e + 2]};
+      edges[(size_t)e].inliers = 0;
+      edges[(size_t)e].is_loop = is_loop[e] != 0;
+    }
+    const bool ok = posegraph_optimize_centers(ctx, kfs, edges);
+    for (int k = 0; k < n_kf; k++) { centres3[3 * k] = kfs[(size_t)k].pose.t.x; centres3[3 * k + 1] = kfs[(size_t)k].pose.t.y; centres3[3 * k + 2] = kfs[(size_t)k].pose.t.z; }
+    return ok ? 1 : 0;
+  } catch (const SfmxFailure& e) {
+    return -e.status;
+  } catch (const std::exception&) {
+    return -SFMX_ERR_INVALID;
+  }
 }
 
 // the CLI's file readers on their own (csrc/host/cli_io.hpp), for the surface tests against the reference's readers

@@ -167,3 +167,19 @@ class Tracker:
             self.close()
         except Exception:
             pass
+
+
+def posegraph(ctx: capi.Context, Rs, centres, ei, ej, eR, et, is_loop):
+    """posegraph_optimize_centers (T:1131-1197) of the host library on its own: (ok, centres)"""
+    lib = load_host_library()
+    Rs = np.ascontiguousarray(Rs, np.float64)
+    c = np.ascontiguousarray(centres, np.float64).copy()
+    ei, ej = np.ascontiguousarray(ei, np.int32), np.ascontiguousarray(ej, np.int32)
+    eR, et = np.ascontiguousarray(eR, np.float64), np.ascontiguousarray(et, np.float64)
+    lp = np.ascontiguousarray(is_loop, np.int32)
+    dp, ip = POINTER(c_double), POINTER(c_int)
+    rc = lib.sfmx_host_posegraph(ctx.h_, c_int(len(c)), Rs.ctypes.data_as(dp), c.ctypes.data_as(dp), c_int(len(ei)), ei.ctypes.data_as(ip),
+                                 ej.ctypes.data_as(ip), eR.ctypes.data_as(dp), et.ctypes.data_as(dp), lp.ctypes.data_as(ip))
+    if rc < 0:
+        raise capi.SfmxError(-rc, "posegraph_optimize_centers")
+    return rc, c

@@ -451,6 +451,83 @@ def test_solve_dense_blocked_sizes(ctx):
         H.assert_bits_equal(x, ex, "rank-deficient blocked", nan_equal=True)
 
 
+def test_solve_dense_has_no_size_cliff(ctx, monkeypatch):
+    """n > 6400: the back-substitution's x and staged rows no longer fit in LDS and move to a global scratch buffer -- same
+    subtraction chain (dense.hpp:86-91), still bit-exact.  The global path at small n (forced), then for real at n = 6600
+    on a banded system (the oracle skips exact-zero multipliers, dense.hpp:80, so it finishes in seconds; the device
+    code runs its full dense schedule either way)."""
+    rng = np.random.default_rng(31)
+    monkeypatch.setenv("SFMX_BACKSUB_LDS_MAX_N", "64")
+    for n in (97, 300, 513):
+        A = rng.normal(size=(n, n))
+        b = rng.normal(size=n)
+        rc, x = ctx.solve_dense(A, b)
+        erc, ex = H.solve_gauss(O, "orc", A, b)
+        assert rc == erc == 0
+        H.assert_bits_equal(x, ex, f"global back-substitution n={n}")
+    monkeypatch.delenv("SFMX_BACKSUB_LDS_MAX_N")
+    n, bw = 6600, 24
+    A = np.zeros((n, n))
+    for d in range(-bw, bw + 1):
+        v = rng.normal(size=n - abs(d))
+        A[np.arange(max(0, -d), min(n, n - d)), np.arange(max(0, d), min(n, n + d))] = v
+    A[np.arange(n), np.arange(n)] += 3.0 * bw ** 0.5
+    b = rng.normal(size=n)
+    rc, x = ctx.solve_dense(A, b)
+    erc, ex = H.solve_gauss(O, "orc", A, b)
+    assert rc == erc == 0
+    H.assert_bits_equal(x, ex, "n = 6600 > LDS limit")
+
+
+def _pose_graph(N, loops, seed, break_at=None):
+    """keyframes on a noisy ring, odometry edges i -> i+1 and `loops` loop edges; break_at: drop that odometry edge"""
+    rng = np.random.default_rng(seed)
+    Rs = np.zeros((N, 9))
+    C = np.zeros((N, 3))
+    for k in range(N):
+        R, t = synth.ring_pose(0.05 * k)
+        Rs[k] = R.T.ravel()                     # camera -> world
+        C[k] = -R.T @ t + rng.normal(size=3) * 1e-3
+    ei, ej, eR, et, lp = [], [], [], [], []
+    pairs = [(i, i + 1, 0) for i in range(N - 1) if i != break_at]
+    for _ in range(loops):
+        a = int(rng.integers(0, N - 8))
+        pairs.append((a, int(rng.integers(a + 6, N)), 1))
+    for i, j, l in pairs:
+        Rw_i, Rw_j = Rs[i].reshape(3, 3), Rs[j].reshape(3, 3)
+        R_ji = Rw_j.T @ Rw_i                    # i -> j
+        t_ji = Rw_j.T @ (C[i] - C[j]) + rng.normal(size=3) * 1e-3
+        t_ji /= np.linalg.norm(t_ji)
+        ei.append(i); ej.append(j); eR.append(R_ji.ravel()); et.append(t_ji); lp.append(l)
+    return Rs, C, np.array(ei, np.int32), np.array(ej, np.int32), np.array(eR), np.array(et), np.array(lp, np.int32)
+
+
+@pytest.mark.parametrize("N", [300, 1000, 3000])
+def test_posegraph_structured_solver_vs_dense_oracle(ctx, N, monkeypatch):
+    """posegraph_optimize_centers (T:1131-1197) with the structured FP64-MFMA solver (tolerance mode, the product path above
+    3N = 6400 unknowns) against the oracle's dense 3N x 3N solve_gauss: n = 900, 3000, 9000 unknowns, centres within
+    1e-9 relative; a graph with a keyframe cut off from node 0 is skipped by both."""
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    Rs, C, ei, ej, eR, et, lp = _pose_graph(N, max(4, N // 40), 2)
+    ok_o, Co = H.posegraph(O, "orc", Rs, C, ei, ej, eR, et, lp)
+    monkeypatch.setenv("SFMX_POSEGRAPH_SOLVER", "structured")
+    ok_s, Cs = pipe.posegraph(ctx, Rs, C, ei, ej, eR, et, lp)
+    assert ok_o == 1 and ok_s == 1
+    scale = np.abs(Co - C).max()
+    assert scale > 1e-6  # the solve must actually move the centres
+    assert np.abs(Cs - Co).max() <= 1e-9 * max(scale, np.abs(Co).max()), np.abs(Cs - Co).max()
+    if N <= 1000:  # the bit-exact dense path on the same input
+        monkeypatch.setenv("SFMX_POSEGRAPH_SOLVER", "dense")
+        ok_d, Cd = pipe.posegraph(ctx, Rs, C, ei, ej, eR, et, lp)
+        assert ok_d == 1
+        H.assert_bits_equal(Cd, Co, "dense pose-graph path")
+        monkeypatch.setenv("SFMX_POSEGRAPH_SOLVER", "structured")
+    Rs, C, ei, ej, eR, et, lp = _pose_graph(N, 0, 3, break_at=N // 2)  # two components: singular
+    ok_o, _ = H.posegraph(O, "orc", Rs, C, ei, ej, eR, et, lp)
+    ok_s, Cs = pipe.posegraph(ctx, Rs, C, ei, ej, eR, et, lp)
+    assert ok_o == 0 and ok_s == 0 and np.array_equal(Cs, C)
+
+
 def _c4_like_problem(W, P, seed):
     rng = np.random.default_rng(seed)
     pw = np.zeros((W, 12))
