@@ -238,13 +238,17 @@ __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const d
 // wave 0 run the add chains over the previous tile.  Missing second addends are +0.0 (identity, see above); "b -= G*bp"
 // is evaluated as b += (-(G*bp)), which is the same IEEE operation.
 #define BAR_COLS 16
-#define BAR_TP 256
+#define BAR_NBUF 3                    // LDS tiles in rotation: one being summed, two on their way
 #define BAR_Q (256 / BAR_COLS)        // point phases per tile pass
-#define BAR_K (BAR_TP / BAR_Q)        // rows per thread and tile
+// LDS: 2 arrays x 3 tiles x 64 rows x 16 columns x 8 B = 48 KiB per workgroup (the 256-row double buffer of round 1
+// took 128 KiB: such a workgroup could not start on a CU that still held KLT workgroups, and the kernel took 2-3 x
+// longer inside the pipeline than alone).  Loads run TWO tiles ahead of the add chains.
+template <int BAR_TP>  // contribution rows per tile
 __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
                                                    double* __restrict__ b) {
-  __shared__ double sv[2][BAR_TP][BAR_COLS];
-  __shared__ double su[2][BAR_TP][BAR_COLS];
+  constexpr int BAR_K = BAR_TP / BAR_Q;  // rows per thread and tile
+  __shared__ double sv[BAR_NBUF][BAR_TP][BAR_COLS];
+  __shared__ double su[BAR_NBUF][BAR_TP][BAR_COLS];
   const int D = 6 * W, CS = ba_row_stride(W), NE = D * D + D;
   const int tid = threadIdx.x, col = tid % BAR_COLS, q = tid / BAR_COLS;
   const int e_raw = blockIdx.x * BAR_COLS + col;
@@ -279,15 +283,15 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
     }
   };
   double acc = 0.0;
-  if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
+  for (int t = 0; t < 2 && t < ntiles; t++) {  // prologue: tiles 0 and 1
+    load_tile(t);
+    store_tile(t);
   }
   __syncthreads();
   for (int t = 0; t < ntiles; t++) {
-    if (t + 1 < ntiles) load_tile(t + 1);
+    if (t + 2 < ntiles) load_tile(t + 2);  // in flight while tile t is summed (tile t+1 already sits in LDS)
     if (tid < BAR_COLS) {
-      const int buf = t & 1, cnt = min(BAR_TP, P - t * BAR_TP);
+      const int buf = t % BAR_NBUF, cnt = min(BAR_TP, P - t * BAR_TP);
       int pp = 0;
       if (any_two) {
         for (; pp + 8 <= cnt; pp += 8) {
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
         for (; pp < cnt; pp++) acc += sv[buf][pp][col];
       }
     }
-    if (t + 1 < ntiles) store_tile((t + 1) & 1);
+    if (t + 2 < ntiles) store_tile((t + 2) % BAR_NBUF);  // that buffer held tile t-1, summed before the previous barrier
     __syncthreads();
   }
   if (tid < BAR_COLS && valid) {
@@ -922,7 +926,7 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
   SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
   SFMX_PROF(c, KID_BA_REDUCE,
-            (k_ba_reduce<<<(D * D + D + BAR_COLS - 1) / BAR_COLS, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b)));
+            (k_ba_reduce<64><<<(D * D + D + BAR_COLS - 1) / BAR_COLS, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b)));
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;

@@ -1494,7 +1494,6 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           else task();
         }
       }
-      if (!looped) join_b();
       if (kfs.size() >= 1) {  // triangulate new points (T:1801-1813)
         const auto th0 = Clock::now();
         // The DLT solves (libm Jacobi) are independent: gather the jobs in the reference's iteration
@@ -1515,6 +1514,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           jobs.push_back(TriJob{tid, &kv.second, &hist, &kfs[(size_t)id0].pose, pl, V3{}, true});
         }
         clk.tri_iter += since(th0);
+        // the walk above only reads the track histories; the solves below read the keyframe poses BA(k-1) refines
+        if (!looped) join_b();
         const auto ts0 = Clock::now();
         ThreadPool::instance().parallel_for((int)jobs.size(), [&](int i) {
           TriJob& j = jobs[(size_t)i];
@@ -1530,6 +1531,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         }
         clk.tri_insert += since(ti0);
         clk.host += since(th0);
+      } else if (!looped) {
+        join_b();
       }
       kfs.push_back(std::move(kf));
       kf_desc.push_back(new_desc);
