@@ -321,8 +321,12 @@ def main():
             "k_ba_reduce": (1.0 * 600 * (36 * 36 + 36), 8.0 * 600 * (36 * 36 + 36 + 48)),
             "k_shi_score": (260.0 * w * h, 9.0 * w * h),
             "k_downsample2": (4.0 * 0.3125 * w * h, 1.3125 * w * h),
+            "solve": (2.0 / 3.0 * 36 ** 3, 8.0 * (36 * 36 + 2 * 36)),
         }
-        dom = max(kern, key=lambda k: kern[k][0]) if kern else "k_klt_track"
+        # "shi fixpoint" is a GROUP of ~20 launches timed as one interval (and, with timing on, issued without the hipGraph that
+        # normally replays them): it is reported, but the roofline object is about a single kernel
+        single = {k: v for k, v in kern.items() if not k.startswith("shi fixpoint")}
+        dom = max(single, key=lambda k: single[k][0]) if single else "k_klt_track"
         dom_us, dom_calls = kern.get(dom, (0.0, 0))
         avg_us = dom_us / dom_calls if dom_calls else 0.0
         alg_flop, alg_bytes = alg.get(dom.split(" ")[0], (None, None))
@@ -345,8 +349,12 @@ def main():
                             valu_issue = dict(source=os.path.basename(metas[-1]).replace("_pmc_meta.json", "_pmc_summary.json"),
                                               valu_wave_insts_per_lk_step=round(row["SQ_INSTS_VALU_avg"] / meta["klt_lk_steps"], 1),
                                               waves=int(row.get("SQ_WAVES_avg", 0)),
-                                              valu_busy_frac=(round(row["SQ_ACTIVE_INST_VALU_avg"] / row["SQ_BUSY_CYCLES_avg"], 4)
-                                                              if "SQ_ACTIVE_INST_VALU_avg" in row and row.get("SQ_BUSY_CYCLES_avg") else None))
+                                              # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles summed over the waves:
+                                              # the share of a wave's lifetime in which it is issuing vector instructions
+                                              valu_active_over_wave_cycles=(round(row["SQ_ACTIVE_INST_VALU_avg"] / row["SQ_WAVE_CYCLES_avg"], 4)
+                                                                            if "SQ_ACTIVE_INST_VALU_avg" in row and row.get("SQ_WAVE_CYCLES_avg") else None),
+                                              issue_stalled_over_wave_cycles=(round(row["SQ_WAIT_INST_ANY_avg"] / row["SQ_WAVE_CYCLES_avg"], 4)
+                                                                              if "SQ_WAIT_INST_ANY_avg" in row and row.get("SQ_WAVE_CYCLES_avg") else None))
         except Exception:
             traffic, valu_issue = None, None
         roofline = dict(bound="valu_fp64", achieved=None if ach_tf is None else round(ach_tf, 4), peak=FP64_VALU_PEAK_TF, unit="TFLOP/s",

@@ -22,6 +22,7 @@
 // Algorithmic bytes per BA iteration: 20*R + 24*P + 96*W read, 8*(D^2+D) written.
 #include "sfmx_internal.h"
 
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 
@@ -914,14 +915,28 @@ __global__ void k_ba_damp_gauge(double* __restrict__ S, double* __restrict__ b, 
   S[(size_t)i * D + i] = v;
 }
 
+// dx | status of one BA step straight into pinned host memory, then a sequence word (system-scope release): the host
+// polls that word instead of going through a DMA copy and a stream synchronisation (~25 us per BA iteration)
+__global__ void k_ba_publish(const double* __restrict__ work, int D, double* __restrict__ host_out, unsigned long long seq) {
+  for (int i = threadIdx.x; i <= D; i += blockDim.x) host_out[i] = work[i];  // [D] holds the status word
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + D + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
-                           double huber, double lambda, int damp, KernelTimer& t) {
+                           double huber, double lambda, int damp, KernelTimer& t, bool zero_copy_poses = false) {
   SFMX_HIP(c, c->h[0].ensure((size_t)q->W * 96));
   memcpy(c->h[0].p, poses_wc, (size_t)q->W * 96);
-  SFMX_HIP(c, hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
+  // zero_copy_poses: k_ba_points reads the 96 W bytes straight out of the pinned staging buffer (the caller does not touch
+  // it again before it has seen this step's result); otherwise one DMA copy into HBM first
+  const double* d_poses = zero_copy_poses ? c->h[0].as<double>() : q->poses;
+  if (!zero_copy_poses) SFMX_HIP(c, hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
   const int D = 6 * q->W;
   t.start();
-  SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, q->poses, q->X, q->obs_ptr, q->obs_li,
+  SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li,
                                                                                 q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of)));
   const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
   SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
@@ -1029,14 +1044,38 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
                  double lambda, double* dx_out) {
   SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
   const int D = 6 * q->W;
+  static const bool no_poll = getenv("SFMX_BA_NO_POLL") != nullptr;
+  const bool poll = !c->timing && !no_poll;  // the event timers need the stream synchronisation
   KernelTimer t(c);
-  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t);
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t, poll);
   if (rc) return rc;
   int* dstatus = reinterpret_cast<int*>(q->work + D);
   rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
   if (rc) return rc;
   int status = 0;
-  SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 8));
+  SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 32));
+  if (poll) {
+    double* hout = c->h[1].as<double>();
+    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(hout + D + 1);
+    const unsigned long long seq = ++c->ba_seq;
+    *flag = 0;  // (a freshly grown buffer holds arbitrary bytes)
+    k_ba_publish<<<1, 64, 0, c->stream>>>(q->work, D, hout, seq);
+    SFMX_HIP(c, hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+        SFMX_HIP(c, hipStreamSynchronize(c->stream));  // an error (or a very slow device): let the runtime report it
+        if (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq)
+          return sfmx_fail(c, SFMX_ERR_HIP, "BA step result never arrived", hipSuccess);
+      }
+    }
+    c->ba_upload_in_flight = false;  // everything queued before the solve has completed
+    memcpy(dx_out, hout, (size_t)D * 8);
+    memcpy(&status, hout + D, 4);
+    return status ? SFMX_ERR_SINGULAR : SFMX_OK;
+  }
   SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, q->work, (size_t)D * 8 + 4, hipMemcpyDeviceToHost, c->stream));  // dx | status
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   c->ba_upload_in_flight = false;

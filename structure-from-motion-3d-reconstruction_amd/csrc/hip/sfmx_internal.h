@@ -83,6 +83,7 @@ struct sfmx_ctx {
   int resident_points = 0;  // #correspondences left in d[0]/d[1] by the last RANSAC call
   int shi_full_count = 0;   // #candidate scores left in d[6] by the last pruned Shi-Tomasi call
   bool shi_keys_in_flight = false;
+  unsigned long long ba_seq = 0;      // sequence number of the last BA step result published into pinned memory
   bool ba_upload_in_flight = false;  // sfmx_ba_reset's transfer out of h[4] has not been waited for yet
   DevBuf wl[4];             // Shi-Tomasi work lists (2), sweep counters, disc offset table
   int wl_md = 0, wl_ntaps = 0;
