@@ -22,5 +22,12 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY
 echo "pmc passes done"
 python tools/summarize_profiles.py "$TAG" "$OUT/bench_trace" "$OUT/pmc"
 python tools/microbench.py > "profiles/${TAG}_microbench.txt" 2>&1
+echo "microbench done"
+python tools/bench_c3.py --frames 100 > "profiles/${TAG}_c3_prefix_line.json" 2> "$OUT/c3.err"
+python bench.py --mode ba-sharded --steps 10 --warmup 2 > "profiles/${TAG}_ba_sharded_1gpu_line.json" 2> "$OUT/ba_sharded.err"
+python tools/posegraph_c5.py > "profiles/${TAG}_posegraph_c5.txt" 2> "$OUT/pg.err"
+python tools/ransac_cond_probe.py > "profiles/${TAG}_ransac_cond_probe.txt" 2> "$OUT/cond.err"
+SFMX_KLT_STAMPS=1 python tools/klt_stamps.py 2>&1 | grep -v amdgpu.ids > "profiles/${TAG}_klt_stamps.txt"
+echo "extras done"
 mkdir -p "gpurun_out/profiles_$TAG" && cp profiles/${TAG}_* "gpurun_out/profiles_$TAG/"
 echo "profiles written: $(ls profiles | grep "^$TAG" | tr '\n' ' ')"
