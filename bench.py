@@ -238,7 +238,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.mode == "sharded-sequence":
-        comms = tuple(importlib.import_module(PKG + ".dist").make_comms(3, local_rank))
+        comms = tuple(importlib.import_module(PKG + ".dist").make_comms(4, local_rank))
 
     def measure(n_seq, n_warm, n_steps):
         """n_seq sequences in flight (one host thread + context each): wall time of n_steps passes of every sequence.
@@ -382,7 +382,7 @@ def main():
                                        if args.mode == "sharded-sequence" else f"sequences x{world * S}")},
             "frames_per_s": round(args.frames * args.steps * (1 if args.mode == "sharded-sequence" else world) * S / dt, 2),
             "keyframes_per_step": int(round(kf_total / max(1, args.steps) / (1 if args.mode == "sharded-sequence" else world))), "map_points": st["n_points"], "passes_bit_identical": bool(identical),
-            "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_wall", "sec_total", "sec_setup", "sec_klt", "sec_shi", "sec_shi_wait", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_pf_busy", "sec_pf_gpu", "sec_pf_replay", "sec_lane_a_busy", "sec_lane_b_busy", "sec_lane_c_busy", "sec_join_wait", "sec_ba_gather", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_feed_wait")},
+            "host_seconds_per_step": {k: round(st[k], 4) for k in ("sec_wall", "sec_total", "sec_setup", "sec_klt", "sec_shi", "sec_shi_wait", "sec_shi_gpu", "sec_shi_replay", "sec_ransac", "sec_ba", "sec_upload", "sec_host", "sec_desc", "sec_bookkeeping", "sec_r_pre", "sec_r_gpu", "sec_r_verify", "sec_r_decomp", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_pf_busy", "sec_pf_gpu", "sec_pf_replay", "sec_lane_a_busy", "sec_lane_b_busy", "sec_lane_c_busy", "sec_lane_e_busy", "sec_join_wait", "sec_ba_gather", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_feed_wait")},
             "counters_per_step": {k: int(st[k]) for k in ("klt_calls", "tracks_in", "lk_steps", "ransac_calls", "ransac_points", "ransac_verified", "ransac_cert_misses", "ba_calls", "ba_iters", "shi_calls", "shi_memo_hits", "shi_prefetched", "shi_fallbacks")},
             "roofline": roofline,
         }

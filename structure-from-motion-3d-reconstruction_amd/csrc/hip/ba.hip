@@ -44,6 +44,7 @@ struct sfmx_ba_problem {
   double* b = nullptr;        // [D]
   double* work = nullptr;     // solve scratch: dx [D] + status
   double* contrib = nullptr;  // [P][CS] per-point contribution rows
+  unsigned* ticket = nullptr;  // finished-workgroup counter of the fused reduce + solve (zero between launches)
 };
 
 // dense.hpp:96-119
@@ -91,15 +92,11 @@ __device__ __forceinline__ void ba_accumulate_slot(double* __restrict__ A, const
     }
 }
 
-__global__ __launch_bounds__(64) void k_ba_points(int W, int P, int MS, const double* __restrict__ poses, const double* __restrict__ X,
-                                                  const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
-                                                  const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
-                                                  double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of) {
-  __shared__ double sp[BA_MAX_W * 12];
-  for (int i = threadIdx.x; i < W * 12; i += blockDim.x) sp[i] = poses[i];
-  __syncthreads();
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
+// per-point records (T:894-1047) of point p: slots in first-observation order, Hxx | bx | Hxp, then G = Hxp Hpp^-1 and G*bp
+__device__ __forceinline__ void ba_point_record(int p, int W, int MS, const double* __restrict__ sp, const double* __restrict__ X,
+                                                const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
+                                                const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy, double huber,
+                                                double* __restrict__ rec, int8_t* __restrict__ slot_of) {
   int8_t* so = slot_of + (size_t)p * W;
   for (int i = 0; i < W; i++) so[i] = -1;
   const int o0 = obs_ptr[p], o1 = obs_ptr[p + 1];
@@ -192,14 +189,74 @@ __global__ __launch_bounds__(64) void k_ba_points(int W, int P, int MS, const do
   }
 }
 
-// Per-point contribution rows.  Layout of one row (CS = D*D + 36*W + 2*D doubles):
-//   [0, D*D)              Schur term  G_a * Hxp_b^T  of S element (i,j)   (T:1049-1055), +0.0 if a pose misses the point
-//   [D*D, D*D+36W)        Hxx term of the diagonal block of pose A         (T:1017)
-//   [.., +D) and [.., +D) bx (T:1018) and G*bp (T:1039-1041)
-// A missing contribution is stored as +0.0: the running sums start at +0.0 and can never become -0.0,
-// so adding +0.0 is the identity and the reduction needs no branches.
 __device__ __forceinline__ int ba_row_stride(int W) { return 36 * W * W + 36 * W + 12 * W; }
 
+// k_ba_points: BA_PTS points per workgroup.  Phase 1: one lane per point writes the point's records (a serial chain of
+// dependent FP64 operations in the reference's order).  Phase 2: all 256 threads spread the records of these points into
+// their contribution rows C[p][.] (layout of one row, CS = D*D + 36 W + 2 D doubles):
+//   [0, D*D)              Schur term  G_a . Hxp_b  of S element (i,j)   (T:1049-1055), +0.0 if a pose misses the point
+//   [D*D, D*D+36W)        Hxx term of the diagonal block of pose A         (T:1017)
+//   [.., +D) and [.., +D) bx (T:1018) and G*bp (T:1039-1041)
+// A missing contribution is stored as +0.0: the running sums of k_ba_reduce start at +0.0 and can never become -0.0,
+// so adding +0.0 is the identity and the reduction needs no branches.  (The expansion used to be a launch of its own.)
+// Two shapes: <4, 256> with the expansion (windows of a few hundred points: one launch less on the BA chain), and
+// <64, 64> without it (C == nullptr) followed by k_ba_expand over the whole device (tens of thousands of points, C4).
+#define BA_PTS 4
+#define BA_MERGED_EXPAND_MAX_P 4096
+template <int PTS, int NT>
+__global__ __launch_bounds__(NT) void k_ba_points(int W, int P, int MS, const double* __restrict__ poses, const double* __restrict__ X,
+                                                  const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
+                                                  const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
+                                                  double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C) {
+  __shared__ double sp[BA_MAX_W * 12];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < W * 12; i += NT) sp[i] = poses[i];
+  __syncthreads();
+  const int p0 = blockIdx.x * PTS;
+  if (tid < PTS && p0 + tid < P) ba_point_record(p0 + tid, W, MS, sp, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of);
+  if (C == nullptr) return;
+  __syncthreads();  // the records and slot tables of this workgroup's points are visible to all its threads
+  const int D = 6 * W, CS = ba_row_stride(W);
+  const int np = min(PTS, P - p0);
+  for (int e = tid; e < CS; e += NT) {
+    // which slot(s) and which doubles inside them feed row element e (the same for every point)
+    int pa, pb = -1, off_a, off_b = 0;
+    if (e < D * D) {
+      const int i = e / D, j = e % D;
+      pa = i / 6; pb = j / 6;
+      off_a = 60 + (i % 6) * 3; off_b = 42 + (j % 6) * 3;
+    } else if (e < D * D + 36 * W) {
+      const int k = e - D * D;
+      pa = k / 36; off_a = k % 36;
+    } else if (e < D * D + 36 * W + D) {
+      const int i = e - (D * D + 36 * W);
+      pa = i / 6; off_a = 36 + (i % 6);
+    } else {
+      const int i = e - (D * D + 36 * W + D);
+      pa = i / 6; off_a = 78 + (i % 6);
+    }
+    for (int pl = 0; pl < np; pl++) {
+      const int p = p0 + pl;
+      const int8_t* so = slot_of + (size_t)p * W;
+      const double* base = rec + (size_t)p * MS * BA_SLOT;
+      const int sa = so[pa];
+      double v = 0.0;
+      if (pb >= 0) {
+        const int sb = so[pb];
+        if (sa >= 0 && sb >= 0) {
+          const double* g = base + (size_t)sa * BA_SLOT + off_a;
+          const double* h = base + (size_t)sb * BA_SLOT + off_b;
+          v = g[0] * h[0] + g[1] * h[1] + g[2] * h[2];
+        }
+      } else if (sa >= 0) {
+        v = base[(size_t)sa * BA_SLOT + off_a];
+      }
+      C[(size_t)p * CS + e] = v;
+    }
+  }
+}
+
+// the expansion as a launch of its own (large problems): one thread per (point, row element)
 __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
                                                    double* __restrict__ C) {
   const int D = 6 * W, CS = ba_row_stride(W);
@@ -231,104 +288,6 @@ __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const d
     if (sa >= 0) v = base[(size_t)sa * BA_SLOT + 78 + (i % 6)];
   }
   C[(size_t)p * CS + e] = v;
-}
-
-// Ordered column sums.  The add chain of one element of S / b over the points is strictly serial (reference order),
-// but its operands are not: a workgroup owns BAR_COLS neighbouring elements, all 256 threads stream the next tile of
-// BAR_TP contribution rows into LDS (32 independent loads per thread in flight, 128-byte segments) while 16 lanes of
-// wave 0 run the add chains over the previous tile.  Missing second addends are +0.0 (identity, see above); "b -= G*bp"
-// is evaluated as b += (-(G*bp)), which is the same IEEE operation.
-#define BAR_COLS 16
-#define BAR_NBUF 3                    // LDS tiles in rotation: one being summed, two on their way
-#define BAR_Q (256 / BAR_COLS)        // point phases per tile pass
-// LDS: 2 arrays x 3 tiles x 64 rows x 16 columns x 8 B = 48 KiB per workgroup (the 256-row double buffer of round 1
-// took 128 KiB: such a workgroup could not start on a CU that still held KLT workgroups, and the kernel took 2-3 x
-// longer inside the pipeline than alone).  Loads run TWO tiles ahead of the add chains.
-template <int BAR_TP>  // contribution rows per tile
-__global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
-                                                   double* __restrict__ b) {
-  constexpr int BAR_K = BAR_TP / BAR_Q;  // rows per thread and tile
-  __shared__ double sv[BAR_NBUF][BAR_TP][BAR_COLS];
-  __shared__ double su[BAR_NBUF][BAR_TP][BAR_COLS];
-  const int D = 6 * W, CS = ba_row_stride(W), NE = D * D + D;
-  const int tid = threadIdx.x, col = tid % BAR_COLS, q = tid / BAR_COLS;
-  const int e_raw = blockIdx.x * BAR_COLS + col;
-  const bool valid = e_raw < NE;
-  const int e = valid ? e_raw : NE - 1;
-  const bool is_b = e >= D * D;
-  const int i = is_b ? e - D * D : e / D;
-  const int j = is_b ? 0 : e % D;
-  const bool diag_blk = (!is_b) && (i / 6 == j / 6);
-  // first / second addend of this element inside a contribution row
-  const int o1 = is_b ? (D * D + 36 * W + i) : (D * D + (i / 6) * 36 + (i % 6) * 6 + (j % 6));
-  const int o2 = is_b ? (D * D + 36 * W + D + i) : e;
-  const bool two = is_b || diag_blk;
-  const bool any_two = __any(two);  // uniform over the block: every wave holds the same BAR_COLS columns
-  const int ntiles = (P + BAR_TP - 1) / BAR_TP;
-  double rv[BAR_K], ru[BAR_K];
-  auto load_tile = [&](int t) {
-#pragma unroll
-    for (int k = 0; k < BAR_K; k++) {
-      const int p = min(t * BAR_TP + k * BAR_Q + q, P - 1);
-      const double* row = C + (size_t)p * CS;
-      const double v = row[o2];
-      rv[k] = is_b ? -v : v;
-      ru[k] = two ? row[o1] : 0.0;
-    }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int k = 0; k < BAR_K; k++) {
-      sv[buf][k * BAR_Q + q][col] = rv[k];
-      su[buf][k * BAR_Q + q][col] = ru[k];
-    }
-  };
-  double acc = 0.0;
-  for (int t = 0; t < 2 && t < ntiles; t++) {  // prologue: tiles 0 and 1
-    load_tile(t);
-    store_tile(t);
-  }
-  __syncthreads();
-  for (int t = 0; t < ntiles; t++) {
-    if (t + 2 < ntiles) load_tile(t + 2);  // in flight while tile t is summed (tile t+1 already sits in LDS)
-    if (tid < BAR_COLS) {
-      const int buf = t % BAR_NBUF, cnt = min(BAR_TP, P - t * BAR_TP);
-      int pp = 0;
-      if (any_two) {
-        for (; pp + 8 <= cnt; pp += 8) {
-          double u[8], v[8];
-#pragma unroll
-          for (int k = 0; k < 8; k++) { u[k] = su[buf][pp + k][col]; v[k] = sv[buf][pp + k][col]; }
-#pragma unroll
-          for (int k = 0; k < 8; k++) { acc += u[k]; acc += v[k]; }  // S += Hxx ; S += G_a Hxp_b^T (reference ADDS, Q6) | b += bx ; b -= G*bp
-        }
-        for (; pp < cnt; pp++) { acc += su[buf][pp][col]; acc += sv[buf][pp][col]; }
-      } else {
-        for (; pp + 16 <= cnt; pp += 16) {
-          double v[16];
-#pragma unroll
-          for (int k = 0; k < 16; k++) v[k] = sv[buf][pp + k][col];
-#pragma unroll
-          for (int k = 0; k < 16; k++) acc += v[k];
-        }
-        for (; pp < cnt; pp++) acc += sv[buf][pp][col];
-      }
-    }
-    if (t + 2 < ntiles) store_tile((t + 2) % BAR_NBUF);  // that buffer held tile t-1, summed before the previous barrier
-    __syncthreads();
-  }
-  if (tid < BAR_COLS && valid) {
-    if (is_b) {
-      if (damp && i < 6) acc = 0.0;  // T:1070
-      b[i] = acc;
-    } else {
-      if (damp && i == j) {
-        acc += lambda;          // T:1064
-        if (i < 6) acc += 1e9;  // T:1069
-      }
-      S[(size_t)i * D + j] = acc;
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------ dense solve
@@ -465,17 +424,6 @@ __global__ __launch_bounds__(64) void k_solve_wave(const double* __restrict__ Ai
   if (lane < n) x[lane] = xs[lane];
 }
 
-// k_solve_regs<N> (N = 6*W for the usual windows): ONE wavefront, lane = matrix row held in REGISTERS (the k and j
-// loops are fully unrolled, so every a[j] is a fixed VGPR); LDS only carries the pivot row of each step.  Compared with
-// k_solve_wave this removes the dependent LDS round trips of the elimination (the dominant cost: ~3500 cycles per step).
-//   rows are never moved: each lane tracks the POSITION its row currently has in the reference's matrix; a row swap
-//     (dense.hpp:69-72) exchanges two positions, and "first strictly larger" = smallest position among the maxima;
-//   pivot   : |a[k]| of the lanes at positions >= k, DPP wave-max, DPP wave-min of the candidates' positions;
-//   scale   : the pivot lane spills its row (and b as column N) to LDS, lane j divides element j (one IEEE division
-//             instruction for the whole row), every lane reads the normalised row back as broadcasts;
-//   eliminate: lanes at positions > k with |f| >= 1e-18: a[j] -= f * r[j] in registers;
-//   back-substitution: the lane at position i runs the reference's ascending-j subtraction chain over products
-//             a[j]*x[j] that every lane forms for its own row as soon as x[j] exists.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_min_step_i32(int m) {
   const int t = __builtin_amdgcn_update_dpp(m, m, CTRL, ROW_MASK, 0xF, false);
@@ -494,96 +442,287 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-template <int N>
-__global__ __launch_bounds__(64) void k_solve_regs(const double* __restrict__ Ain, const double* __restrict__ bin, double* __restrict__ x,
-                                                   int* __restrict__ status) {
+// wave-wide maximum of 32-bit unsigned keys (0 = identity, so the DPP move folds into v_max_u32); result in every lane's SGPR copy
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax_step(unsigned m) {
+  const unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, CTRL, ROW_MASK, 0xF, false);
+  return t > m ? t : m;
+}
+__device__ __forceinline__ unsigned wave_umax_u32(unsigned m) {
+  m = dpp_umax_step<0xB1, 0xF>(m);
+  m = dpp_umax_step<0x4E, 0xF>(m);
+  m = dpp_umax_step<0x141, 0xF>(m);
+  m = dpp_umax_step<0x140, 0xF>(m);
+  m = dpp_umax_step<0x142, 0xA>(m);
+  m = dpp_umax_step<0x143, 0xC>(m);
+  return (unsigned)__builtin_amdgcn_readlane((int)m, 63);
+}
+// one wave: its LDS operations execute in program order, so a compiler-level fence is all the phases need
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// k_solve_regs<N>: ONE wavefront, lane = row, the row's N coefficients + b in registers (static indices: the k loop
+// is unrolled).  Rows never move: a row swap exchanges the POSITIONS two lanes stand for.  Per pivot step:
+//   pivot     |a_ik| are non-negative, so their order is the order of their bit patterns: two 6-step DPP maxima over
+//             32-bit halves (NaN keys are 0: `v > best` is never true for them), first position among equal maxima;
+//   normalise the pivot lane writes its raw row to LDS, lane j divides element j by the pivot (one IEEE division per
+//             lane) and stores the quotient as row k of R: R ends up holding the normalised rows BY POSITION, which is
+//             all the back substitution reads; the pivot lane itself never takes its row back;
+//   eliminate every remaining lane: a_ij = a_ij - f_i * R[k][j], operands broadcast from LDS, separate multiply and
+//             subtract; nothing else touches the registers (no selects).
+// `ws` is N * ((N+1)|1) + N + 2 doubles of LDS.  Callable from wave 0 of any workgroup (no s_barrier inside).
+template <int N, bool STAMP = false>
+__device__ __forceinline__ void solve_regs_wave(const double* __restrict__ Ain, const double* __restrict__ bin, double* __restrict__ x,
+                                                int* __restrict__ status, double* __restrict__ ws, int lane,
+                                                unsigned long long* __restrict__ stamps = nullptr, double* x_lane = nullptr,
+                                                int* status_out = nullptr) {
+  if constexpr (STAMP) { if (lane == 0) stamps[0] = __builtin_amdgcn_s_memtime(); }
   static_assert(N >= 2 && N <= 62, "b rides along as column N: lane N must exist");
-  constexpr int LD = N | 1;
-  __shared__ double stage[N * LD];
-  __shared__ double rowbuf[N + 2];
-  const int lane = threadIdx.x;
-  for (int e = lane; e < N * N; e += 64) stage[(e / N) * LD + (e % N)] = Ain[e];
-  __syncthreads();
+  constexpr int LD = (N + 1) | 1;
+  double* R = ws;
+  double* raw = ws + N * LD;
   const int row = lane < N ? lane : N - 1;  // lanes >= N shadow the last row and never take part
   double a[N];
+  {  // every lane fetches its own row: N/2 independent 16-byte loads in flight (rows are 16-byte aligned: N is even)
+    static_assert(N % 2 == 0, "16-byte row loads");
+    const double2* src = reinterpret_cast<const double2*>(Ain + (size_t)row * N);
 #pragma unroll
-  for (int j = 0; j < N; j++) a[j] = stage[row * LD + j];
+    for (int j = 0; j < N / 2; j++) {
+      const double2 t = src[j];
+      a[2 * j] = t.x;
+      a[2 * j + 1] = t.y;
+    }
+  }
   double bv = bin[row];
+  if constexpr (STAMP) { if (lane == 0) stamps[1] = __builtin_amdgcn_s_memtime(); }
   int pos = lane < N ? lane : 0x3fffffff;  // position of this lane's row; finished pivot rows keep position k
   bool done = lane >= N;                   // true once the row has been a pivot row
-  double xr = 0.0;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    // ---- pivot (dense.hpp:61-67)
+    if constexpr (STAMP) { if (lane == 0) stamps[2 + k] = __builtin_amdgcn_s_memtime(); }
+    // ---- pivot (dense.hpp:61-67), kept on the vector side: the scalar unit only sees the rare cases
     const bool cand_row = !done;
-    const double v = cand_row ? fabs(a[k]) : -1.0;
-    const int lane_k = (int)__builtin_ctzll(__ballot(cand_row && pos == k));
-    const double akk0 = readlane_f64(v, lane_k);
-    int pivpos = k, lane_p = lane_k;
-    double best = akk0;
-    if (akk0 == akk0) {  // a NaN on the diagonal stays the pivot: `v > NaN` is never true
-      const double m = wave_max_f64((v == v) ? v : -1.0);
-      const unsigned long long hits = __ballot(cand_row && v == m);
-      if (__builtin_popcountll(hits) == 1) {  // the usual case: a unique maximum
-        lane_p = (int)__builtin_ctzll(hits);
-        pivpos = __builtin_amdgcn_readlane(pos, lane_p);
-      } else {  // ties: the reference keeps the first one in position order
-        pivpos = wave_min_i32((cand_row && v == m) ? pos : 0x7fffffff);
-        lane_p = (int)__builtin_ctzll(__ballot(cand_row && pos == pivpos));
+    const double v = fabs(a[k]);
+    const bool at_k = cand_row && pos == k;
+    const bool v_nan = v != v;
+    bool is_p;   // this lane's row is the pivot row of step k
+    int pivpos;  // the position it comes from
+    if (__ballot(at_k && v_nan)) {  // a NaN on the diagonal stays the pivot: `v > NaN` is never true, `NaN < 1e-15` neither
+      is_p = at_k;
+      pivpos = k;
+    } else {
+      const bool ok = cand_row && !v_nan;
+      const unsigned hi = ok ? (unsigned)__double2hiint(v) : 0u;
+      const unsigned mh = wave_umax_u32(hi);
+      bool hit = ok && hi == mh;  // never empty: the row at position k is ok
+      unsigned long long hits = __ballot(hit);
+      if (__builtin_popcountll(hits) != 1) {  // rare: the upper halves tie; lower halves, then the first position (the reference's `>`)
+        const unsigned lo = hit ? (unsigned)__double2loint(v) : 0u;
+        const unsigned ml = wave_umax_u32(lo);
+        hit = hit && lo == ml;
+        const int first = wave_min_i32(hit ? pos : 0x7fffffff);
+        hit = cand_row && pos == first;
+        hits = __ballot(hit);
       }
-      best = m;
+      if (__ballot(hit && v < 1e-15)) {
+        if (lane == 0) status[0] = 1;
+        if (status_out) *status_out = 1;
+        return;
+      }
+      is_p = hit;
+      pivpos = __builtin_amdgcn_readlane(pos, (int)__builtin_ctzll(hits));
     }
-    if (best < 1e-15) {
-      if (lane == 0) status[0] = 1;
-      return;
-    }
+    if constexpr (STAMP) { if (lane == 0) stamps[40 + 3 * k] = __builtin_amdgcn_s_memtime(); }
     // ---- row swap (dense.hpp:69-72) = exchange of positions
-    if (lane == lane_k) pos = pivpos;
-    if (lane == lane_p) { pos = k; done = true; }
-    // ---- normalise the pivot row (dense.hpp:74-76) through LDS, transposed: one division per lane
-    if (lane == lane_p) {
+    if (at_k) pos = pivpos;
+    if (is_p) { pos = k; done = true; }
+    // ---- normalise the pivot row (dense.hpp:74-76), transposed through LDS: one division per lane.  The copy starts at
+    // an even column so that it is made of aligned 16-byte stores for either parity of k (one stale element rides along)
+    if (is_p) {
 #pragma unroll
-      for (int j = k; j < N; j++) rowbuf[j] = a[j];
-      rowbuf[N] = bv;
+      for (int j = (k & ~1); j < N; j++) raw[j] = a[j];
+      raw[N] = bv;
     }
-    __syncthreads();
-    {
-      const double akk = rowbuf[k];
-      const int j = lane < k ? k : (lane > N ? N : lane);
-      const double q = rowbuf[j] / akk;
-      __syncthreads();
-      if (lane >= k && lane <= N) rowbuf[lane] = q;
-    }
-    __syncthreads();
-    // ---- eliminate (dense.hpp:78-83); the pivot lane takes its normalised row back
-    const bool is_p = lane == lane_p;
+    wave_sync();
+    if constexpr (STAMP) { if (lane == 0) stamps[41 + 3 * k] = __builtin_amdgcn_s_memtime(); }
+    const double akk = raw[k];
+    const double q = raw[lane <= k ? k : (lane > N ? N : lane)] / akk;  // lane j: element j of the normalised row (b at lane N)
+    if (lane > k && lane <= N) R[k * LD + lane] = q;                  // kept by position for the back substitution
+    // ---- eliminate (dense.hpp:78-83); column k itself becomes f - f*1 and is never read again.  The normalised row
+    // reaches every lane as scalar operands (v_readlane from the lane that divided it): no LDS round trip, no waits
+    if constexpr (STAMP) { if (lane == 0) stamps[42 + 3 * k] = __builtin_amdgcn_s_memtime() + (unsigned long long)(q == 123.0); }
     const double f = a[k];
-    const bool upd = !done && !(fabs(f) < 1e-18);
-    if (upd || is_p) {
-      const double g = is_p ? 0.0 : f;  // pivot lane: a[j] = r[j] (selected below), others: a[j] - f * r[j]
+    if (!done && !(fabs(f) < 1e-18)) {
 #pragma unroll
-      for (int j = k; j < N; j++) {
-        const double r = rowbuf[j];
-        a[j] = is_p ? r : a[j] - g * r;
-      }
-      const double rb = rowbuf[N];
-      bv = is_p ? rb : bv - g * rb;
+      for (int j = k + 1; j < N; j++) a[j] = a[j] - f * readlane_f64(q, j);
+      bv = bv - f * readlane_f64(q, N);
     }
-    __syncthreads();  // rowbuf is rewritten by the next step
   }
-  // ---- back substitution (dense.hpp:86-91): after the loop every lane < N sits at a distinct position
+  // ---- back substitution (dense.hpp:86-91): lane i now reads the normalised row of POSITION i
+  wave_sync();
+  if constexpr (STAMP) { if (lane == 0) stamps[2 + N] = __builtin_amdgcn_s_memtime(); }
+#pragma unroll
+  for (int j = 1; j < N; j++) a[j] = R[row * LD + j];  // entries j <= row are stale and never used
+  const double s0 = R[row * LD + N];
+  double xr = 0.0;
 #pragma unroll
   for (int i = N - 1; i >= 0; i--) {
-    const int lane_i = (int)__builtin_ctzll(__ballot(pos == i));
-    double s = bv;
+    double s = s0;
 #pragma unroll
     for (int j = i + 1; j < N; j++) s -= a[j];  // a[j] already holds A(.,j)*x[j] for this lane's row
-    const double xi = readlane_f64(s, lane_i);
-    a[i] = a[i] * xi;  // the product the reference forms at dense.hpp:89, for every row at once
+    const double xi = readlane_f64(s, i);
+    if (i > 0) a[i] = a[i] * xi;  // the product the reference forms at dense.hpp:89, for every row at once
     if (lane == i) xr = xi;
   }
   if (lane == 0) status[0] = 0;
   if (lane < N) x[lane] = xr;
+  if (x_lane) *x_lane = xr;
+  if (status_out) *status_out = 0;
+  if constexpr (STAMP) { if (lane == 0) stamps[3 + N] = __builtin_amdgcn_s_memtime(); }
+}
+template <int N>
+__global__ __launch_bounds__(64) void k_solve_regs(const double* __restrict__ Ain, const double* __restrict__ bin, double* __restrict__ x,
+                                                   int* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) double ws[N * ((N + 1) | 1) + N + 2];
+  solve_regs_wave<N>(Ain, bin, x, status, ws, (int)threadIdx.x);
+}
+// diagnostic instantiation (SFMX_SOLVE_STAMPS=1): s_memtime at entry, after the load, before every pivot step, before and
+// after the back substitution
+template <int N>
+__global__ __launch_bounds__(64) void k_solve_regs_stamps(const double* __restrict__ Ain, const double* __restrict__ bin, double* __restrict__ x,
+                                                          int* __restrict__ status, unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(16))) double ws[N * ((N + 1) | 1) + N + 2];
+  solve_regs_wave<N, true>(Ain, bin, x, status, ws, (int)threadIdx.x, stamps);
+}
+
+// Ordered column sums of the contribution rows = the reduced camera system S | b (T:1017-1018, 1039-1055).  The add
+// chain of one element over the points is strictly serial (reference order), its operands are not: a workgroup owns
+// BAR_COLS neighbouring elements, all 256 threads stream the next tile of BAR_TP contribution rows into LDS (independent
+// loads, 128-byte segments), two tiles ahead of the 16 lanes of wave 0 that run the add chains.  Missing second addends are
+// +0.0 (identity, see k_ba_points); "b -= G*bp" is evaluated as b += (-(G*bp)), which is the same IEEE operation.
+// SOLVE_N = 6 W (36, 60): the workgroup that finishes LAST (device-scope ticket) goes on to solve S dx = b with
+// solve_regs_wave and publishes dx | status (to `work`, and to pinned host memory with a sequence word when `host_out`
+// is given): one BA iteration is two launches (points + expansion, reduction + solve) instead of five.
+#define BAR_COLS 16
+#define BAR_NBUF 3                    // LDS tiles in rotation: one being summed, two on their way
+#define BAR_Q (256 / BAR_COLS)        // point phases per tile pass
+// LDS: 2 arrays x 3 tiles x 64 rows x 16 columns x 8 B = 48 KiB per workgroup (a 128 KiB double buffer could not start
+// on a CU that still held KLT workgroups, and the kernel took 2-3 x longer inside the pipeline than alone).
+template <int BAR_TP, int SOLVE_N>
+__global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
+                                                   double* __restrict__ S, double* __restrict__ b,
+                                                   unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
+                                                   unsigned long long seq) {
+  constexpr int BAR_K = BAR_TP / BAR_Q;  // rows per thread and tile
+  constexpr int TILE_DOUBLES = 2 * BAR_NBUF * BAR_TP * BAR_COLS;
+  constexpr int SOLVE_DOUBLES = SOLVE_N > 0 ? SOLVE_N * ((SOLVE_N + 1) | 1) + SOLVE_N + 2 : 0;
+  __shared__ __attribute__((aligned(16))) double lds[TILE_DOUBLES > SOLVE_DOUBLES ? TILE_DOUBLES : SOLVE_DOUBLES];
+  double (*sv)[BAR_TP][BAR_COLS] = reinterpret_cast<double (*)[BAR_TP][BAR_COLS]>(lds);
+  double (*su)[BAR_TP][BAR_COLS] = reinterpret_cast<double (*)[BAR_TP][BAR_COLS]>(lds + BAR_NBUF * BAR_TP * BAR_COLS);
+  const int D = 6 * W, CS = ba_row_stride(W), NE = D * D + D;
+  const int tid = threadIdx.x, col = tid % BAR_COLS, q = tid / BAR_COLS;
+  const int e_raw = blockIdx.x * BAR_COLS + col;
+  const bool valid = e_raw < NE;
+  const int e = valid ? e_raw : NE - 1;
+  const bool is_b = e >= D * D;
+  const int i = is_b ? e - D * D : e / D;
+  const int j = is_b ? 0 : e % D;
+  const bool diag_blk = (!is_b) && (i / 6 == j / 6);
+  // first / second addend of this element inside a contribution row
+  const int o1 = is_b ? (D * D + 36 * W + i) : (D * D + (i / 6) * 36 + (i % 6) * 6 + (j % 6));
+  const int o2 = is_b ? (D * D + 36 * W + D + i) : e;
+  const bool two = is_b || diag_blk;
+  const bool any_two = __any(two);  // uniform over the block: every wave holds the same BAR_COLS columns
+  const int ntiles = (P + BAR_TP - 1) / BAR_TP;
+  double rv[BAR_K], ru[BAR_K];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int k = 0; k < BAR_K; k++) {
+      const int p = min(t * BAR_TP + k * BAR_Q + q, P - 1);
+      const double* row = C + (size_t)p * CS;
+      const double v = row[o2];
+      rv[k] = is_b ? -v : v;
+      ru[k] = two ? row[o1] : 0.0;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < BAR_K; k++) {
+      sv[buf][k * BAR_Q + q][col] = rv[k];
+      su[buf][k * BAR_Q + q][col] = ru[k];
+    }
+  };
+  double acc = 0.0;
+  for (int t = 0; t < 2 && t < ntiles; t++) {  // prologue: tiles 0 and 1
+    load_tile(t);
+    store_tile(t);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; t++) {
+    if (t + 2 < ntiles) load_tile(t + 2);  // in flight while tile t is summed (tile t+1 already sits in LDS)
+    if (tid < BAR_COLS) {
+      const int buf = t % BAR_NBUF, cnt = min(BAR_TP, P - t * BAR_TP);
+      int pp = 0;
+      if (any_two) {
+        for (; pp + 8 <= cnt; pp += 8) {
+          double u[8], v[8];
+#pragma unroll
+          for (int k = 0; k < 8; k++) { u[k] = su[buf][pp + k][col]; v[k] = sv[buf][pp + k][col]; }
+#pragma unroll
+          for (int k = 0; k < 8; k++) { acc += u[k]; acc += v[k]; }  // S += Hxx ; S += G_a Hxp_b^T (reference ADDS, Q6) | b += bx ; b -= G*bp
+        }
+        for (; pp < cnt; pp++) { acc += su[buf][pp][col]; acc += sv[buf][pp][col]; }
+      } else {
+        for (; pp + 16 <= cnt; pp += 16) {
+          double v[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) v[k] = sv[buf][pp + k][col];
+#pragma unroll
+          for (int k = 0; k < 16; k++) acc += v[k];
+        }
+        for (; pp < cnt; pp++) acc += sv[buf][pp][col];
+      }
+    }
+    if (t + 2 < ntiles) store_tile((t + 2) % BAR_NBUF);  // that buffer held tile t-1, summed before the previous barrier
+    __syncthreads();
+  }
+  if (tid < BAR_COLS && valid) {
+    if (is_b) {
+      if (damp && i < 6) acc = 0.0;  // T:1070
+      b[i] = acc;
+    } else {
+      if (damp && i == j) {
+        acc += lambda;          // T:1064
+        if (i < 6) acc += 1e9;  // T:1069
+      }
+      S[(size_t)i * D + j] = acc;
+    }
+  }
+  if constexpr (SOLVE_N > 0) {
+    // ---- the last workgroup to get here solves the system the others have just finished writing
+    __shared__ int is_last;
+    if (tid < BAR_COLS) __threadfence();  // this workgroup's elements are visible device-wide before its ticket is
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (!is_last || tid >= 64) return;
+    __threadfence();  // acquire: S | b of every other workgroup
+    if (tid == 0) *ticket = 0;  // for the next launch on this stream
+    double xr = 0.0;
+    int st = 0;
+    int* dstatus = reinterpret_cast<int*>(work + SOLVE_N);
+    solve_regs_wave<SOLVE_N>(S, b, work, dstatus, lds, tid, nullptr, &xr, &st);
+    if (host_out) {  // dx | status | sequence word in pinned host memory: the host polls the word (no DMA copy, no stream sync)
+      if (tid < SOLVE_N) host_out[tid] = xr;
+      if (tid == 0) *reinterpret_cast<int*>(host_out + SOLVE_N) = st;
+      __threadfence_system();
+      wave_sync();
+      if (tid == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + SOLVE_N + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ blocked dense solve
@@ -856,9 +995,27 @@ static int launch_solve(sfmx_ctx* c, const double* dA, const double* db, int n, 
   return rc;
 }
 static int launch_solve_kernels(sfmx_ctx* c, const double* dA, const double* db, int n, double* dx, int* dstatus) {
-  if (n == 36) {  // window of 6 (the reference default) and of 10 (C4): rows in registers
+  static const bool stamps = getenv("SFMX_SOLVE_STAMPS") != nullptr;
+  const bool rows16 = ((reinterpret_cast<uintptr_t>(dA) & 15) == 0);  // k_solve_regs fetches rows with 16-byte loads
+  if (n == 36 && stamps && rows16) {  // diagnostic: per-phase cycle stamps of one solve on stderr
+    unsigned long long* d = nullptr;
+    unsigned long long h[40 + 3 * 36] = {};
+    if (hipMalloc(&d, sizeof(h)) == hipSuccess) {
+      (void)hipMemsetAsync(d, 0, sizeof(h), c->stream);
+      k_solve_regs_stamps<36><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus, d);
+      (void)hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(d);
+      fprintf(stderr, "solve36 stamps: load %llu |", h[1] - h[0]);
+      for (int k = 0; k < 36; k++) fprintf(stderr, " %llu", h[3 + k] - h[2 + k]);
+      fprintf(stderr, " | backsub %llu | total %llu\n", h[39] - h[38], h[39] - h[0]);
+      for (int k = 0; k < 36; k += 7)
+        fprintf(stderr, "  step %2d: pivot %llu | row write %llu | division %llu | eliminate %llu\n", k, h[40 + 3 * k] - h[2 + k],
+                h[41 + 3 * k] - h[40 + 3 * k], h[42 + 3 * k] - h[41 + 3 * k], h[3 + k] - h[42 + 3 * k]);
+    }
+  } else if (n == 36 && rows16) {  // window of 6 (the reference default) and of 10 (C4): rows in registers
     k_solve_regs<36><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus);
-  } else if (n == 60) {
+  } else if (n == 60 && rows16) {
     k_solve_regs<60><<<1, 64, 0, c->stream>>>(dA, db, dx, dstatus);
   } else if (n <= SOLVE_WAVE_MAX_N) {
     k_solve_wave<<<1, 64, 0, c->stream>>>(dA, db, n, dx, dstatus);
@@ -926,8 +1083,12 @@ __global__ void k_ba_publish(const double* __restrict__ work, int D, double* __r
   }
 }
 
+// fused: 0 = sums only; otherwise the last workgroup of the reduction also solves and publishes (D = 36 / 60 only: see
+// ba_can_fuse_solve), to q->work and, if host_out is given, to pinned host memory with sequence word `seq`
+static bool ba_can_fuse_solve(const sfmx_ba_problem* q) { return q->W == 6 || q->W == 10; }
 static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
-                           double huber, double lambda, int damp, KernelTimer& t, bool zero_copy_poses = false) {
+                           double huber, double lambda, int damp, KernelTimer& t, bool zero_copy_poses = false, bool fused_solve = false,
+                           double* host_out = nullptr, unsigned long long seq = 0) {
   SFMX_HIP(c, c->h[0].ensure((size_t)q->W * 96));
   memcpy(c->h[0].p, poses_wc, (size_t)q->W * 96);
   // zero_copy_poses: k_ba_points reads the 96 W bytes straight out of the pinned staging buffer (the caller does not touch
@@ -936,12 +1097,28 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   if (!zero_copy_poses) SFMX_HIP(c, hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
   const int D = 6 * q->W;
   t.start();
-  SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li,
-                                                                                q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of)));
-  const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
-  SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
-  SFMX_PROF(c, KID_BA_REDUCE,
-            (k_ba_reduce<64><<<(D * D + D + BAR_COLS - 1) / BAR_COLS, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b)));
+  static const char* expand_env = getenv("SFMX_BA_EXPAND");  // "split" / "merged": A/B and tests
+  const bool merged = expand_env ? expand_env[0] == 'm' : q->P <= BA_MERGED_EXPAND_MAX_P;
+  if (merged) {
+    SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<BA_PTS, 256><<<(q->P + BA_PTS - 1) / BA_PTS, 256, 0, c->stream>>>(
+                                    q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib)));
+  } else {
+    SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<64, 64><<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx,
+                                                                                         fy, cx, cy, huber, q->rec, q->slot_of, nullptr)));
+    const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
+    SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
+  }
+  const int nwg = (D * D + D + BAR_COLS - 1) / BAR_COLS;
+  if (fused_solve && q->W == 6) {
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+                                                                              q->ticket, q->work, host_out, seq)));
+  } else if (fused_solve && q->W == 10) {
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 60><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+                                                                              q->ticket, q->work, host_out, seq)));
+  } else {
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+                                                                             nullptr, nullptr, nullptr, 0)));
+  }
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;
@@ -967,6 +1144,7 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
                            (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8 + (size_t)D * 8, 16, (size_t)D * 8 + 64,
                            (size_t)P * CS * 8};
   for (int i = 0; i < 11; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
+  q->ticket = q->bufs[8].as<unsigned>();
   q->contrib = q->bufs[10].as<double>();
   char* in = q->bufs[0].as<char>();
   q->X = reinterpret_cast<double*>(in + o_x); q->obs_uv = reinterpret_cast<double*>(in + o_uv);
@@ -987,6 +1165,7 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
     memcpy(st + o_li, obs_li, (size_t)R * 4);
   }
   SFMX_HIP(c, hipMemcpyAsync(in, st, in_bytes, hipMemcpyHostToDevice, c->stream));
+  SFMX_HIP(c, hipMemsetAsync(q->ticket, 0, 16, c->stream));
   c->ba_upload_in_flight = true;  // cleared by the first build / step, which wait for the stream
   return SFMX_OK;
 }
@@ -1045,22 +1224,28 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
   SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
   const int D = 6 * q->W;
   static const bool no_poll = getenv("SFMX_BA_NO_POLL") != nullptr;
+  static const bool no_fuse = getenv("SFMX_BA_NO_FUSE") != nullptr;  // A/B and tests: reduce, solve and publish as separate launches
   const bool poll = !c->timing && !no_poll;  // the event timers need the stream synchronisation
+  const bool fuse = ba_can_fuse_solve(q) && !no_fuse;
   KernelTimer t(c);
-  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t, poll);
-  if (rc) return rc;
-  int* dstatus = reinterpret_cast<int*>(q->work + D);
-  rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
-  if (rc) return rc;
-  int status = 0;
   SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 32));
+  double* hout = c->h[1].as<double>();
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(hout + D + 1);
+  const unsigned long long seq = ++c->ba_seq;
+  if (poll) *flag = 0;  // (a freshly grown buffer holds arbitrary bytes)
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t, poll, fuse, poll ? hout : nullptr, seq);
+  if (rc) return rc;
+  if (!fuse) {
+    int* dstatus = reinterpret_cast<int*>(q->work + D);
+    rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
+    if (rc) return rc;
+  }
+  int status = 0;
   if (poll) {
-    double* hout = c->h[1].as<double>();
-    volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(hout + D + 1);
-    const unsigned long long seq = ++c->ba_seq;
-    *flag = 0;  // (a freshly grown buffer holds arbitrary bytes)
-    k_ba_publish<<<1, 64, 0, c->stream>>>(q->work, D, hout, seq);
-    SFMX_HIP(c, hipGetLastError());
+    if (!fuse) {
+      k_ba_publish<<<1, 64, 0, c->stream>>>(q->work, D, hout, seq);
+      SFMX_HIP(c, hipGetLastError());
+    }
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {

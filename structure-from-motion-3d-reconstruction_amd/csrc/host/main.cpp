@@ -252,15 +252,15 @@ int main(int argc, char** argv) {
     if (rc != SFMX_OK) throw std::runtime_error("no usable MI355X (gfx950) device: sfmx_ctx_create failed (there is no CPU fallback)");
     struct CtxGuard { sfmx_ctx* c; ~CtxGuard() { sfmx_ctx_destroy(c); } } guard{ctx};
     struct Comms {
-      sfmx_comm* c[3] = {nullptr, nullptr, nullptr};
+      sfmx_comm* c[4] = {nullptr, nullptr, nullptr, nullptr};
       ~Comms() { for (sfmx_comm* m : c) sfmx_comm_destroy(m); }
     } comms;
     if (dist_world > 1) {
       const char* idf = std::getenv("SFMX_DIST_ID_FILE");
       if (!idf || dist_rank < 0 || dist_rank >= dist_world) throw std::runtime_error("SFMX_DIST_WORLD needs SFMX_DIST_RANK in range and SFMX_DIST_ID_FILE");
-      std::string ids((size_t)3 * SFMX_COMM_ID_BYTES, '\0');
+      std::string ids((size_t)4 * SFMX_COMM_ID_BYTES, '\0');
       if (dist_rank == 0) {
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < 4; k++)
           if (sfmx_comm_get_unique_id(&ids[(size_t)k * SFMX_COMM_ID_BYTES]) != SFMX_OK) throw std::runtime_error("RCCL is not available (sfmx_comm_get_unique_id)");
         const std::string tmp = std::string(idf) + ".tmp";
         { std::ofstream f(tmp, std::ios::binary); f.write(ids.data(), (std::streamsize)ids.size()); }
@@ -273,12 +273,13 @@ int main(int argc, char** argv) {
           std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
       }
-      for (int k = 0; k < 3; k++)
+      for (int k = 0; k < 4; k++)
         if (sfmx_comm_create(device, &ids[(size_t)k * SFMX_COMM_ID_BYTES], dist_rank, dist_world, &comms.c[k]) != SFMX_OK)
           throw std::runtime_error("sfmx_comm_create failed (RCCL)");
       pc.comm_ba = comms.c[0];
       pc.comm_ransac_a = comms.c[1];
       pc.comm_ransac_c = comms.c[2];
+      pc.comm_ransac_e = comms.c[3];
     }
     const bool speaker = dist_rank == 0;  // every rank computes the same result; one of them reports it
 

@@ -320,6 +320,8 @@ void ContextPool::clear() {
   free_.clear();
 }
 void PooledCtx::free_pyramids() {
+  if (ba) sfmx_ba_destroy(ctx, ba);
+  ba = nullptr;
   if (pyr) sfmx_pyramid_destroy(ctx, pyr);
   pyr = nullptr;
   for (sfmx_pyramid* p : ring) sfmx_pyramid_destroy(ctx, p);
@@ -792,7 +794,10 @@ void MapState::add_obs(int tid, int kf_id, V2 uv) {
 }
 
 // ------------------------------------------------------------------------------------------ BA
-GpuBundleAdjuster::~GpuBundleAdjuster() { sfmx_ba_destroy(ctx_, prob_); }
+GpuBundleAdjuster::~GpuBundleAdjuster() {
+  if (keep_) *keep_ = prob_;  // stays with the pooled context: no hipFree / hipMalloc per run
+  else sfmx_ba_destroy(ctx_, prob_);
+}
 
 BaJob GpuBundleAdjuster::gather(const Mat3& K, const std::vector<Keyframe>& kfs, const MapState& map, const BAConfig& cfg) {
   BaJob job;
@@ -1108,7 +1113,7 @@ void StageClock::add(const StageClock& o) {
   ba_iters += o.ba_iters; klt_calls += o.klt_calls; ransac_verified += o.ransac_verified; ransac_cert_misses += o.ransac_cert_misses; shi_fallbacks += o.shi_fallbacks;
   shi_calls += o.shi_calls; shi_memo_hits += o.shi_memo_hits; shi_prefetched += o.shi_prefetched;
   shi_wait += o.shi_wait; setup += o.setup;
-  pf_busy += o.pf_busy; pf_gpu += o.pf_gpu; pf_replay += o.pf_replay; lane_b_busy += o.lane_b_busy; lane_c_busy += o.lane_c_busy;
+  pf_busy += o.pf_busy; pf_gpu += o.pf_gpu; pf_replay += o.pf_replay; lane_b_busy += o.lane_b_busy; lane_c_busy += o.lane_c_busy; lane_e_busy += o.lane_e_busy;
   lane_a_busy += o.lane_a_busy;
   join_wait += o.join_wait; ba_gather += o.ba_gather; m_step += o.m_step; m_ransac += o.m_ransac; m_kf += o.m_kf; feed_wait += o.feed_wait;
 }
@@ -1227,6 +1232,10 @@ void FrameFeeder::release_upto(int frame) {
 void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>& meta, const Mat3& K, const PipelineConfig& cfg,
                   PipelineResult& out, void (*echo)(const std::string&)) {
   const auto t_all = Clock::now();
+  struct PhaseMark {  // SFMX_TRACE_PHASES=1: prints when the objects declared AFTER it have been destroyed
+    const char* what; Clock::time_point t0;
+    ~PhaseMark() { if (std::getenv("SFMX_TRACE_PHASES")) std::fprintf(stderr, "phase %-22s %8.3f ms\n", what, std::chrono::duration<double>(Clock::now() - t0).count() * 1e3); }
+  };
   StageClock& clk = out.clock;
   const int w = src.width(), h = src.height();
   const int dlevel = desc_level(w, h);
@@ -1247,18 +1256,19 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         !std::getenv("SFMX_NO_CTX_POOL")) {
       warmed_devices.push_back(dev);
       const char* order = std::getenv("SFMX_LANE_ORDER");
-      if (!order) order = "TBPCA";
+      if (!order) order = "TBPCAE";
       std::vector<PooledCtx*> made;
       for (const char* c = order; *c; ++c) {
         const int role = *c == 'P' ? ContextPool::PREFETCH : *c == 'T' ? ContextPool::TRACKER : *c == 'B' ? ContextPool::LANE_B
-                         : *c == 'C' ? ContextPool::LANE_C : *c == 'A' ? ContextPool::LANE_A : 0;
+                         : *c == 'C' ? ContextPool::LANE_C : *c == 'A' ? ContextPool::LANE_A : *c == 'E' ? ContextPool::LANE_E : 0;
         if (role) made.push_back(ContextPool::instance().acquire(dev, 0, role));
       }
       for (PooledCtx* pc : made) ContextPool::instance().release(pc);
     }
   }
-  int prefetch_workers = 1;
+  int prefetch_workers = 2;  // one worker's 0.9 ms per frame was the tracker lane's bound (it waited 26 of 52 ms for corners)
   if (const char* e = std::getenv("SFMX_PREFETCH_WORKERS")) prefetch_workers = std::min(4, std::max(1, std::atoi(e)));
+  PhaseMark pm_prefetch{"~prefetch.. done", t_all};
   std::unique_ptr<CornerPrefetcher> prefetch;
   if (!std::getenv("SFMX_NO_PREFETCH") && std::min(cfg.frames, src.count()) > 1 && cfg.klt.min_distance >= 1 && cfg.klt.min_distance <= 16) {
     prefetch = std::make_unique<CornerPrefetcher>(sfmx_ctx_device(ctx), src, cfg.klt.quality, cfg.klt.min_distance, prefetch_workers, sfmx_get_timing(ctx) != 0);
@@ -1269,6 +1279,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   // Lane A: the frame->frame find_E_ransac (T:1739) is a pure function of the tracker's StepOut (RNG seeded inside, T:657), so
   // it starts as soon as the tracker lane has produced the packet, on a context of its own; the geometry lane picks the result
   // up with the packet (SFMX_NO_RANSAC_LANE=1: computed by the geometry lane itself, as before).
+  PhaseMark pm_lane_a{"~lane_a.. done", t_all};
   StageClock lane_a_clk;
   std::unique_ptr<AsyncLane> lane_a;
   if (track_lane && !std::getenv("SFMX_NO_RANSAC_LANE"))
@@ -1292,6 +1303,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         }
       });
     };
+  PhaseMark pm_feeder{"~feeder.. done", t_all};
   FrameFeeder feeder(ctx, src, cfg.klt, dlevel + 1, dlevel, n_frames, track_lane, prefetch.get(), prefetch_workers + 1, &clk, on_packet);
   CornerDetector geo_det(ctx, &clk);                                  // loop closure: corners of old keyframe images ...
   std::unordered_map<int, std::shared_ptr<const CornerMemo>> kf_corners;  // ... unless their sequence is already known
@@ -1309,23 +1321,35 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   // Lane C: the keyframe->keyframe RANSAC (T:1793; its edge only feeds the pose graph / CSV) and the loop-closure
   // verification of keyframe k (KLT old-keyframe -> new-keyframe + RANSAC, T:1834-1858), whose verdict is only consumed
   // -- pose graph + second BA, T:1859-1863 -- before the next keyframe is built.
-  // SFMX_NO_ASYNC=1 runs everything on this thread (DESIGN.md 4.6).
+  // Lane E: the keyframe->keyframe RANSAC (T:1793).  Its edge feeds nothing but the pose graph and the CSV, so it is not
+  // joined per keyframe at all: the results are appended to `edges` in keyframe order when a loop closure needs them
+  // (finish_loop) and at the end.  SFMX_NO_EDGE_LANE=1 (and a sharded run without a fourth communicator) keeps these on
+  // lane C, joined at every keyframe.
+  // SFMX_NO_ASYNC=1 runs everything on this thread (DESIGN.md 4.7).
   const bool use_lane = !std::getenv("SFMX_NO_ASYNC");
-  StageClock lane_clk, lane_c_clk;
-  std::unique_ptr<AsyncLane> lane, lane_c;
+  PhaseMark pm_lanes{"~lanes B C E.. done", t_all};
+  StageClock lane_clk, lane_c_clk, lane_e_clk;
+  std::unique_ptr<AsyncLane> lane, lane_c, lane_e;
   if (use_lane) {
     lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_B", 0), ContextPool::LANE_B);
     lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_C", 0), ContextPool::LANE_C);
+    if (!std::getenv("SFMX_NO_EDGE_LANE") && (cfg.comm_ransac_c == nullptr || cfg.comm_ransac_e != nullptr))
+      lane_e = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_E", 0), ContextPool::LANE_E);
   }
   if (sfmx_get_timing(ctx)) {  // per-kernel event timing is inherited by the helper contexts
     if (lane) (void)sfmx_set_timing(lane->ctx(), 1);
     if (lane_c) (void)sfmx_set_timing(lane_c->ctx(), 1);
+    if (lane_e) (void)sfmx_set_timing(lane_e->ctx(), 1);
   }
   sfmx_ctx* bctx = lane ? lane->ctx() : ctx;
   StageClock* bclk = lane ? &lane_clk : &clk;
   sfmx_ctx* cctx = lane_c ? lane_c->ctx() : ctx;
   StageClock* cclk = lane_c ? &lane_c_clk : &clk;
-  GpuBundleAdjuster ba(bctx, bclk, cfg.comm_ba);
+  AsyncLane* edge_lane = lane_e ? lane_e.get() : lane_c.get();  // where the keyframe->keyframe RANSAC runs
+  sfmx_ctx* ectx = lane_e ? lane_e->ctx() : cctx;
+  StageClock* eclk = lane_e ? &lane_e_clk : cclk;
+  sfmx_comm* ecomm = lane_e ? cfg.comm_ransac_e : cfg.comm_ransac_c;
+  GpuBundleAdjuster ba(bctx, bclk, cfg.comm_ba, lane ? &lane->pooled()->ba : nullptr);
   sfmx_pyramid* old_pyr_c = nullptr;  // lane C's copy of the old keyframe image
   struct PyrGuardC { sfmx_ctx* c; sfmx_pyramid** p; ~PyrGuardC() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard_c{cctx, &old_pyr_c};
   struct PendingEdge { int i, j; std::optional<RelPose> rel; };
@@ -1333,12 +1357,13 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   BaJob pending_ba;
   struct PendingLoop { bool active = false; int frame = -1, old_kf = -1, new_kf = -1; std::optional<RelPose> rel; } pending_loop;
   struct LaneGuard {  // declared after everything the lanes' tasks reference: drained first when unwinding
-    AsyncLane *l, *m;
+    AsyncLane *l, *m, *e;
     ~LaneGuard() {
       if (l) { try { l->wait(); } catch (...) {} }
       if (m) { try { m->wait(); } catch (...) {} }
+      if (e) { try { e->wait(); } catch (...) {} }
     }
-  } lane_guard{lane.get(), lane_c.get()};
+  } lane_guard{lane.get(), lane_c.get(), lane_e.get()};
   sfmx_pyramid* old_pyr = nullptr;  // loop-closure verification image (T:1834)
   struct Guard { sfmx_ctx* c; sfmx_pyramid** p; ~Guard() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard{ctx, &old_pyr};
 
@@ -1347,17 +1372,23 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   MapState& map = out.map;
   std::vector<PGEdge>& edges = out.edges;
   // Joining is split so that the wait for BA(k) can be pushed as late as the data dependence allows:
-  //   join_c: lane C is done -> append its edge(s); returns true if the loop closure of keyframe k was accepted
+  //   join_c: lane C is done; returns true if the loop closure of keyframe k was accepted
+  //   flush_edges: the keyframe->keyframe edges found so far, appended in keyframe order (T:1798 comes before T:1859)
   //   join_b: lane B is done -> write BA(k)'s poses back
-  //   finish_loop: loop edge + pose graph + second BA (T:1859-1863), needs both
+  //   finish_loop: loop edge + pose graph + second BA (T:1859-1863), needs all three
   std::optional<PendingLoop> accepted_loop;
-  auto join_c = [&]() -> bool {
+  auto flush_edges = [&]() {
     const auto tj = Clock::now();
-    if (lane_c) lane_c->wait();
+    if (edge_lane) edge_lane->wait();
     clk.join_wait += since(tj);
     for (PendingEdge& pe : pending_edges)
       if (pe.rel) edges.push_back(PGEdge{pe.i, pe.j, pe.rel->R_ji, pe.rel->t_ji, (int)pe.rel->inliers.size(), false});
     pending_edges.clear();
+  };
+  auto join_c = [&]() -> bool {
+    const auto tj = Clock::now();
+    if (lane_c) lane_c->wait();
+    clk.join_wait += since(tj);
     if (pending_loop.active) {  // verdict of the loop-closure verification of the last keyframe (T:1858)
       const PendingLoop pl = pending_loop;
       pending_loop = PendingLoop{};
@@ -1375,6 +1406,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   auto finish_loop = [&]() {
     const PendingLoop pl = *accepted_loop;
     accepted_loop.reset();
+    flush_edges();
     edges.push_back(PGEdge{pl.old_kf, pl.new_kf, pl.rel->R_ji, pl.rel->t_ji, (int)pl.rel->inliers.size(), true});
     (void)posegraph_optimize_centers(ctx, kfs, edges);
     ba.run(K, kfs, map, cfg.ba);  // the lanes are idle here: lane B's context is used from this thread
@@ -1383,11 +1415,19 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     const bool looped = join_c();
     join_b();
     if (looped) finish_loop();
+    if (!lane_e) flush_edges();  // without lane E the edges share lane C, which has just been joined
   };
+  PhaseMark pm_maps{"~maps.. done", t_all};
   std::vector<std::vector<float>> kf_desc;
   Arena* arena = out.arena.get();
   // mapped: the track already has a map point (== map.has(tid), kept in the node the walk below touches anyway)
-  struct TrackHist { std::vector<std::pair<int, V2>> obs; bool mapped = false; };
+  // (the observation lists live in the arena too: ~15 000 heap vectors cost 1.7 ms to free at the end of a 47-frame run)
+  using ObsList = std::vector<std::pair<int, V2>, ArenaAlloc<std::pair<int, V2>>>;
+  struct TrackHist {
+    ObsList obs;
+    bool mapped = false;
+    explicit TrackHist(Arena* a) : obs(ArenaAlloc<std::pair<int, V2>>(a)) {}
+  };
   ArenaMap<int, TrackHist> track_hist(0, std::hash<int>(), std::equal_to<int>(), ArenaAlloc<std::pair<const int, TrackHist>>(arena));
   int last_kf_frame = -999999;
   const int frames = cfg.frames;
@@ -1400,6 +1440,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   };
 
   clk.setup = since(t_all);
+  static const bool trace_phases = std::getenv("SFMX_TRACE_PHASES") != nullptr;
+  auto phase = [&](const char* what) { if (trace_phases) std::fprintf(stderr, "phase %-22s %8.3f ms\n", what, since(t_all) * 1e3); };
+  phase("setup done");
   for (int fi = 0; fi < std::min(frames, src.count()); ++fi) {
     if (pending_loop.active && fi >= pending_loop.frame + 2) join_lane();  // its 'current' pyramid is about to be reused
     const auto tm0 = Clock::now();
@@ -1418,7 +1461,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       keep_corners(fi, pkt.corners);
       for (const Track& tr : pkt.tracks) {
         kf.obs.emplace(tr.id, tr.p);
-        track_hist[tr.id].obs.push_back({kf.kf_id, tr.p});
+        track_hist.try_emplace(tr.id, arena).first->second.obs.push_back({kf.kf_id, tr.p});
       }
       kfs.push_back(std::move(kf));
       last_kf_frame = fi;
@@ -1468,7 +1511,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       const auto tb0 = Clock::now();
       for (const Track& tr : pkt.tracks) {
         kf.obs.emplace(tr.id, tr.p);
-        TrackHist& th = track_hist[tr.id];
+        TrackHist& th = track_hist.try_emplace(tr.id, arena).first->second;
         th.obs.push_back({kf.kf_id, tr.p});
         if (th.mapped) map.add_obs(tr.id, kf.kf_id, tr.p);
       }
@@ -1487,10 +1530,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         if (ei.size() >= 80) {
           pending_edges.push_back(PendingEdge{prev_kf.kf_id, kf.kf_id, std::nullopt});
           PendingEdge* slot = &pending_edges.back();  // std::deque: stays valid while later edges are appended
-          auto task = [slot, cctx, cclk, K, comm_c = cfg.comm_ransac_c, ei = std::move(ei), ej = std::move(ej)]() {
-            slot->rel = find_E_ransac_gpu(cctx, K, ei, ej, 2500, 1e-3, 60, cclk, comm_c);
+          auto task = [slot, ectx, eclk, K, ecomm, ei = std::move(ei), ej = std::move(ej)]() {
+            slot->rel = find_E_ransac_gpu(ectx, K, ei, ej, 2500, 1e-3, 60, eclk, ecomm);
           };
-          if (lane_c) lane_c->submit(std::move(task));
+          if (edge_lane) edge_lane->submit(std::move(task));
           else task();
         }
       }
@@ -1498,7 +1541,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         const auto th0 = Clock::now();
         // The DLT solves (libm Jacobi) are independent: gather the jobs in the reference's iteration
         // order, solve them on the host pool, then insert into the map sequentially in that same order.
-        struct TriJob { int tid; TrackHist* th; const std::vector<std::pair<int, V2>>* hist; const Pose* p0; const Pose* pl; V3 X; bool ok; };
+        struct TriJob { int tid; TrackHist* th; const ObsList* hist; const Pose* p0; const Pose* pl; V3 X; bool ok; };
         std::vector<TriJob> jobs;
         for (auto& kv : track_hist) {
           const int tid = kv.first;
@@ -1605,8 +1648,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     emit(fi);
     release_frames(fi);
   }
+  phase("frame loop done");
   join_lane();
+  flush_edges();
+  phase("lanes joined");
   feeder.finish();
+  phase("feeder finished");
   if (lane_a) {
     lane_a->wait();
     clk.lane_a_busy = lane_a->busy_seconds();
@@ -1621,6 +1668,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     if (feeder.threaded()) clk.grab_profile(feeder.ctx());
     if (lane) clk.grab_profile(lane->ctx());
     if (lane_c) clk.grab_profile(lane_c->ctx());
+    if (lane_e) clk.grab_profile(lane_e->ctx());
     if (prefetch) prefetch->grab_profile(clk);
   }
   if (feeder.threaded()) clk.add(feeder.lane_clock());
@@ -1634,7 +1682,14 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     clk.klt += lane_c_clk.klt; clk.klt_kernel_us += lane_c_clk.klt_kernel_us; clk.lk_steps += lane_c_clk.lk_steps;
     clk.tracks_in += lane_c_clk.tracks_in; clk.klt_calls += lane_c_clk.klt_calls;
   }
-  if (lane) {  // lane B's (and, merged above, lane C's) counters
+  if (lane_e) {
+    clk.lane_e_busy = lane_e->busy_seconds();
+    lane_clk.ransac += lane_e_clk.ransac; lane_clk.ransac_kernel_us += lane_e_clk.ransac_kernel_us; lane_clk.ransac_calls += lane_e_clk.ransac_calls;
+    lane_clk.ransac_points += lane_e_clk.ransac_points; lane_clk.ransac_verified += lane_e_clk.ransac_verified;
+    lane_clk.ransac_cert_misses += lane_e_clk.ransac_cert_misses;
+    lane_clk.r_pre += lane_e_clk.r_pre; lane_clk.r_gpu += lane_e_clk.r_gpu; lane_clk.r_verify += lane_e_clk.r_verify; lane_clk.r_decomp += lane_e_clk.r_decomp;
+  }
+  if (lane) {  // lane B's (and, merged above, lane C's and E's) counters
     clk.ba += lane_clk.ba; clk.ba_kernel_us += lane_clk.ba_kernel_us; clk.ba_calls += lane_clk.ba_calls; clk.ba_iters += lane_clk.ba_iters;
     clk.ransac += lane_clk.ransac; clk.ransac_kernel_us += lane_clk.ransac_kernel_us; clk.ransac_calls += lane_clk.ransac_calls;
     clk.ransac_points += lane_clk.ransac_points; clk.ransac_verified += lane_clk.ransac_verified;
@@ -1648,6 +1703,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     prefetch->busy(clk.pf_busy, clk.pf_gpu, clk.pf_replay);  // the worker's tie-order replays count too
     prefetch.reset();
   }
+  phase("prefetch torn down");
   clk.total = since(t_all);
 }
 
@@ -1706,7 +1762,7 @@ struct sfmx_pipeline_cfg {
   double kf_parallax_px;
   int ba_window, ba_iters, ba_max_points;
   double ba_huber, ba_lambda;
-  sfmx_comm *comm_ba, *comm_ransac_a, *comm_ransac_c;  // multi-GPU mode (PipelineConfig); null = unsharded
+  sfmx_comm *comm_ba, *comm_ransac_a, *comm_ransac_c, *comm_ransac_e;  // multi-GPU mode (PipelineConfig); null = unsharded
 };
 struct sfmx_pipeline_stats {
   int n_keyframes, n_points, n_edges, n_frames;
@@ -1719,7 +1775,7 @@ struct sfmx_pipeline_stats {
   unsigned long long ransac_cert_misses;
   double us_kernel[16];
   unsigned long long calls_kernel[16];
-  double sec_lane_a_busy;
+  double sec_lane_a_busy, sec_lane_e_busy;
 };
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
@@ -1754,10 +1810,12 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     pc.kf_min_gap = cfg->kf_min_gap; pc.kf_min_inliers = cfg->kf_min_inliers; pc.kf_parallax_px = cfg->kf_parallax_px;
     pc.ba.window = cfg->ba_window; pc.ba.iters = cfg->ba_iters; pc.ba.max_points = cfg->ba_max_points;
     pc.ba.huber_delta = cfg->ba_huber; pc.ba.lambda = cfg->ba_lambda;
-    pc.comm_ba = cfg->comm_ba; pc.comm_ransac_a = cfg->comm_ransac_a; pc.comm_ransac_c = cfg->comm_ransac_c;
+    pc.comm_ba = cfg->comm_ba; pc.comm_ransac_a = cfg->comm_ransac_a; pc.comm_ransac_c = cfg->comm_ransac_c; pc.comm_ransac_e = cfg->comm_ransac_e;
     PipelineResult res;
+    if (std::getenv("SFMX_TRACE_PHASES")) std::fprintf(stderr, "phase %-22s %8.3f ms (since entry)\n", "inputs wrapped", since(t_wall) * 1e3);
     run_pipeline(ctx, src, meta, K, pc, res);  // returns after its lanes / prefetch contexts are torn down
     const double wall = since(t_wall);
+    if (std::getenv("SFMX_TRACE_PHASES")) std::fprintf(stderr, "phase %-22s %8.3f ms (since entry)\n", "run_pipeline returned", wall * 1e3);
     if (out_dir) write_outputs(out_dir, pc, meta, res);
     if (log && log_cap > 0) std::snprintf(log, (size_t)log_cap, "%s", res.log.c_str());
     if (stats) {
@@ -1770,6 +1828,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
                                    c.m_step, c.m_ransac, c.m_kf, c.feed_wait, c.ransac_cert_misses, {}, {}};
       for (int i = 0; i < 16; i++) { stats->us_kernel[i] = c.kernel_us[i]; stats->calls_kernel[i] = c.kernel_calls[i]; }
       stats->sec_lane_a_busy = c.lane_a_busy;
+      stats->sec_lane_e_busy = c.lane_e_busy;
     }
     if (centres_out)
       for (int k = 0; k < (int)res.kfs.size() && k < centres_cap; k++) {

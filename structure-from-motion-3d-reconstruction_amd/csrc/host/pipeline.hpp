@@ -74,7 +74,7 @@ struct StageClock {
   std::uint64_t ransac_cert_misses = 0;  // a certified inlier count that did not hold (parity fallback taken)
   std::uint64_t ransac_verified = 0, shi_fallbacks = 0, shi_calls = 0, shi_memo_hits = 0, shi_prefetched = 0;
   double shi_wait = 0, setup = 0;
-  double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_a_busy = 0, lane_b_busy = 0, lane_c_busy = 0, join_wait = 0, ba_gather = 0;
+  double pf_busy = 0, pf_gpu = 0, pf_replay = 0, lane_a_busy = 0, lane_b_busy = 0, lane_c_busy = 0, lane_e_busy = 0, join_wait = 0, ba_gather = 0;
   double m_step = 0, m_ransac = 0, m_kf = 0;  // wall time of tracker.step (tracker lane) / frame->frame RANSAC / keyframe block
   double feed_wait = 0;                        // geometry lane waiting for the tracker lane
   // per-kernel GPU time / launches over every context of the run (sfmx_kernel_profile; only with timing enabled)
@@ -102,12 +102,13 @@ struct PooledCtx {
   std::vector<sfmx_pyramid*> ring;  // the tracker lane's pyramids, same life cycle
   int rw = 0, rh = 0, rl = 0;
   const std::vector<sfmx_pyramid*>& pyramid_ring(int w, int h, int levels, int count);
+  sfmx_ba_problem* ba = nullptr;  // lane B's BA problem object (grow-only device buffers), same life cycle
   void free_pyramids();
 };
 class ContextPool {
  public:
   static ContextPool& instance();
-  enum Role { PREFETCH = 1, TRACKER = 2, LANE_B = 3, LANE_C = 4, LANE_A = 5 };
+  enum Role { PREFETCH = 1, TRACKER = 2, LANE_B = 3, LANE_C = 4, LANE_A = 5, LANE_E = 6 };
   PooledCtx* acquire(int device, int priority, int role);
   void release(PooledCtx* pc);  // synchronises the context; the caller's threads must have stopped using it
   void clear();
@@ -377,7 +378,9 @@ struct BaJob {
 class GpuBundleAdjuster {
  public:
   // comm (optional): the window's points are sharded over its ranks, S | b all-reduced per iteration (sfmx_ba_step_sharded)
-  GpuBundleAdjuster(sfmx_ctx* ctx, StageClock* clk, sfmx_comm* comm = nullptr) : ctx_(ctx), clk_(clk), comm_(comm) {}
+  // keep (optional): where the problem object lives between runs (a pooled context); otherwise it is destroyed with this
+  GpuBundleAdjuster(sfmx_ctx* ctx, StageClock* clk, sfmx_comm* comm = nullptr, sfmx_ba_problem** keep = nullptr)
+      : ctx_(ctx), clk_(clk), comm_(comm), prob_(keep ? *keep : nullptr), keep_(keep) {}
   ~GpuBundleAdjuster();
   static BaJob gather(const Mat3& K, const std::vector<Keyframe>& kfs, const MapState& map, const BAConfig& cfg);
   void solve(BaJob& job);
@@ -393,6 +396,7 @@ class GpuBundleAdjuster {
   StageClock* clk_;
   sfmx_comm* comm_ = nullptr;
   sfmx_ba_problem* prob_ = nullptr;
+  sfmx_ba_problem** keep_ = nullptr;
 };
 
 // A second execution lane: one worker thread with its OWN sfmx context (own HIP stream and device buffers).
@@ -438,10 +442,12 @@ struct PipelineConfig {
   double kf_parallax_px = 18.0;
   // Multi-GPU mode (one process per GPU, every rank runs the same sequence): BA points and RANSAC hypotheses are
   // sharded over the ranks of these communicators.  One communicator per lane that issues collectives:
-  // BA (lane B), frame->frame RANSAC (lane A) and keyframe->keyframe / loop-closure RANSAC (lane C).  null = unsharded.
+  // BA (lane B), frame->frame RANSAC (lane A), loop-closure RANSAC (lane C) and keyframe->keyframe RANSAC (lane E; without
+  // comm_ransac_e a sharded run keeps those on lane C).  null = unsharded.
   sfmx_comm* comm_ba = nullptr;
   sfmx_comm* comm_ransac_a = nullptr;
   sfmx_comm* comm_ransac_c = nullptr;
+  sfmx_comm* comm_ransac_e = nullptr;
 };
 struct FrameMeta {
   std::string name;

@@ -19,7 +19,7 @@ class PipelineCfg(ctypes.Structure):
                 ("klt_iters", c_int), ("fb_thresh", c_double), ("kf_min_gap", c_int), ("kf_min_inliers", c_int),
                 ("kf_parallax_px", c_double), ("ba_window", c_int), ("ba_iters", c_int), ("ba_max_points", c_int),
                 ("ba_huber", c_double), ("ba_lambda", c_double),
-                ("comm_ba", c_void_p), ("comm_ransac_a", c_void_p), ("comm_ransac_c", c_void_p)]
+                ("comm_ba", c_void_p), ("comm_ransac_a", c_void_p), ("comm_ransac_c", c_void_p), ("comm_ransac_e", c_void_p)]
 
 
 class PipelineStats(ctypes.Structure):
@@ -39,7 +39,7 @@ class PipelineStats(ctypes.Structure):
                 ("sec_pf_replay", c_double), ("sec_lane_b_busy", c_double), ("sec_lane_c_busy", c_double),
                 ("sec_join_wait", c_double), ("sec_ba_gather", c_double), ("sec_m_step", c_double), ("sec_m_ransac", c_double),
                 ("sec_m_kf", c_double), ("sec_feed_wait", c_double), ("ransac_cert_misses", c_ulonglong),
-                ("us_kernel", c_double * 16), ("calls_kernel", c_ulonglong * 16), ("sec_lane_a_busy", c_double)]
+                ("us_kernel", c_double * 16), ("calls_kernel", c_ulonglong * 16), ("sec_lane_a_busy", c_double), ("sec_lane_e_busy", c_double)]
 
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("us_kernel", "calls_kernel")}
@@ -72,8 +72,8 @@ def load_host_library() -> ctypes.CDLL:
 def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=None, cfg: dict | None = None,
         out_dir: str | None = None, images_dev: int | None = None, shape=None, timing: bool = False, comms=None):
     """Run the per-frame loop.  images: host [F,h,w] u8, or images_dev: device pointer with shape=(F,h,w).
-    comms (optional): (ba, ransac_a, ransac_c) capi.Comm objects -- every rank runs the same sequence, BA points and
-    RANSAC hypotheses are sharded over the ranks."""
+    comms (optional): (ba, ransac_a, ransac_c[, ransac_e]) capi.Comm objects -- every rank runs the same sequence, BA points
+    and RANSAC hypotheses are sharded over the ranks (without the fourth one the keyframe->keyframe RANSAC stays on lane C)."""
     lib = load_host_library()
     if images is not None:
         images = np.ascontiguousarray(images, np.uint8)
@@ -82,7 +82,8 @@ def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=No
         F, h, w = shape
     c = PipelineCfg(**{**DEFAULTS, **(cfg or {})})
     if comms is not None:
-        c.comm_ba, c.comm_ransac_a, c.comm_ransac_c = (m.h_ if m is not None else None for m in comms)
+        hs = [m.h_ if m is not None else None for m in comms] + [None]
+        c.comm_ba, c.comm_ransac_a, c.comm_ransac_c, c.comm_ransac_e = hs[:4]
     arr = (c_char_p * F)(*[str(n).encode() for n in names])
     K = np.ascontiguousarray(K, np.float64).reshape(9)
     lat = np.zeros(F) if lat is None else np.ascontiguousarray(lat, np.float64)

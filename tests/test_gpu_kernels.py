@@ -401,6 +401,46 @@ def test_solve_dense(ctx, golden):
     H.assert_bits_equal(x, ex, "nan solve", nan_equal=True)
 
 
+@pytest.mark.parametrize("n", [36, 60])
+def test_solve_register_kernels_edge_cases(ctx, n):
+    """k_solve_regs<36/60> (the BA windows of 6 and 10 poses): random systems, pivot ties (first position wins), the
+    |f| < 1e-18 skip, NaN on and off the diagonal, zero columns / singular systems, all against the oracle bit for bit."""
+    rng = np.random.default_rng(100 + n)
+    cases = []
+    for t in range(6):
+        cases.append((f"random {t}", rng.normal(size=(n, n)), rng.normal(size=n)))
+    M = rng.normal(size=(n, n))
+    cases.append(("spd", M @ M.T + 1e-3 * np.eye(n), rng.normal(size=n)))
+    A = rng.integers(-3, 4, size=(n, n)).astype(np.float64)  # many equal |values| per column: ties at most steps
+    cases.append(("integer ties", A + 0.0, rng.integers(-5, 6, size=n).astype(np.float64)))
+    A = rng.normal(size=(n, n))
+    A[:, 0] = np.where(np.arange(n) % 2 == 0, 2.5, -2.5)  # every row ties in the first column, signs differ
+    cases.append(("tie column 0", A, rng.normal(size=n)))
+    A = rng.normal(size=(n, n))
+    A[5, :] *= 1e-20
+    A[n - 2, :] *= 1e-19
+    cases.append(("tiny multipliers", A, rng.normal(size=n)))
+    A = rng.normal(size=(n, n))
+    A[7, 3] = np.nan
+    cases.append(("nan off the diagonal", A, np.ones(n)))
+    A = rng.normal(size=(n, n))
+    A[0, 0] = np.nan
+    cases.append(("nan on the first diagonal element", A, np.ones(n)))
+    A = rng.normal(size=(n, n))
+    A[:, 4] = 0.0
+    cases.append(("zero column", A, np.ones(n)))
+    A = rng.normal(size=(n, n))
+    A[n - 1, :] = A[0, :]
+    cases.append(("duplicate row", A, np.ones(n)))
+    cases.append(("identity with signed zeros", np.eye(n) * -1.0 + 0.0 * rng.normal(size=(n, n)), -np.ones(n)))
+    for name, A, b in cases:
+        rc, x = ctx.solve_dense(A, b)
+        erc, ex = H.solve_gauss(O, "orc", A, b)
+        assert (rc != 0) == (erc != 0), name
+        if rc == 0:
+            H.assert_bits_equal(x, ex, f"n={n} {name}", nan_equal=True)
+
+
 def test_solve_dense_blocked_sizes(ctx):
     """n > 64 takes the blocked multi-workgroup elimination (pose graphs: 3 unknowns per keyframe).  Bit-exact against the
     oracle's solve_gauss on sizes around the block edges, on a pose-graph-shaped system, with tied pivots, skipped

@@ -257,7 +257,8 @@ def test_async_lanes_do_not_change_results(tmp_path):
         json.dump(cfgj, f)
     outs = []
     for extra in ({}, {"SFMX_NO_PREFETCH": "1", "SFMX_NO_ASYNC": "1", "SFMX_NO_GRAPH": "1"}, {"SFMX_NO_ASYNC": "1"}, {"SFMX_NO_PREFETCH": "1"},
-                  {"SFMX_NO_TRACK_LANE": "1"}, {"SFMX_NO_TRACK_LANE": "1", "SFMX_NO_PREFETCH": "1", "SFMX_NO_CTX_POOL": "1"}):
+                  {"SFMX_NO_TRACK_LANE": "1"}, {"SFMX_NO_TRACK_LANE": "1", "SFMX_NO_PREFETCH": "1", "SFMX_NO_CTX_POOL": "1"},
+                  {"SFMX_NO_EDGE_LANE": "1"}, {"SFMX_NO_RANSAC_LANE": "1", "SFMX_PREFETCH_WORKERS": "2"}):
         out = os.path.join(root, f"out{len(outs)}")
         p = subprocess.run([pipe.CLI_PATH, root, out, "--config", os.path.join(root, "cfg.json")], capture_output=True, text=True,
                            cwd=root, env={**os.environ, **extra})
