@@ -1143,7 +1143,9 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
   const size_t need[11] = {in_bytes, 16, 16, 16, (size_t)W * 96,
                            (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8 + (size_t)D * 8, 16, (size_t)D * 8 + 64,
                            (size_t)P * CS * 8};
+  const void* ticket_before = q->bufs[8].p;
   for (int i = 0; i < 11; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
+  const bool new_ticket = q->bufs[8].p != ticket_before;  // zeroed once: every launch leaves the counter at zero
   q->ticket = q->bufs[8].as<unsigned>();
   q->contrib = q->bufs[10].as<double>();
   char* in = q->bufs[0].as<char>();
@@ -1165,7 +1167,7 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
     memcpy(st + o_li, obs_li, (size_t)R * 4);
   }
   SFMX_HIP(c, hipMemcpyAsync(in, st, in_bytes, hipMemcpyHostToDevice, c->stream));
-  SFMX_HIP(c, hipMemsetAsync(q->ticket, 0, 16, c->stream));
+  if (new_ticket) SFMX_HIP(c, hipMemsetAsync(q->ticket, 0, 16, c->stream));
   c->ba_upload_in_flight = true;  // cleared by the first build / step, which wait for the stream
   return SFMX_OK;
 }

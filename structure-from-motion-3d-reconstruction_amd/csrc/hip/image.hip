@@ -249,7 +249,9 @@ __global__ void k_row_write(const double* __restrict__ score, int w, int h, cons
 // state: 0 = below threshold, 1 = undecided candidate, 2 = accepted, 3 = rejected.
 __global__ __launch_bounds__(256) void k_shi_init(const double* __restrict__ score, int w, int h,
                                                   const unsigned long long* __restrict__ max_bits, double quality,
-                                                  uint8_t* __restrict__ state) {
+                                                  uint8_t* __restrict__ state, int* __restrict__ zero_ints, int n_zero) {
+  // the work-list counters of the later sweeps start at zero (this used to be a fill launch of its own)
+  if (zero_ints && blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < n_zero) zero_ints[threadIdx.x] = 0;
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= w || y >= h) return;
   const double thr = __longlong_as_double((long long)*max_bits) * quality;
@@ -473,8 +475,16 @@ __global__ void k_flag_row_count(const uint8_t* __restrict__ flag, int w, int* _
 }
 __global__ void k_flag_row_write(const double* __restrict__ score, const uint8_t* __restrict__ flag, int w, const int* __restrict__ row_off,
                                  const int* __restrict__ row_off_all, int cap, uint32_t* __restrict__ cand_xy, double* __restrict__ cand_s,
-                                 int32_t* __restrict__ cand_full, double2* __restrict__ all_keys) {
+                                 int32_t* __restrict__ cand_full, double2* __restrict__ all_keys, const unsigned long long* __restrict__ header,
+                                 char* __restrict__ pin, int spec) {
+  // pin (optional, pinned HOST memory): [0,16) the header {max score bits, #survivors, #candidates}, then the first `spec`
+  // survivors as [xy u32][score f64][full index i32] -- written from here instead of through four DMA copies
+  const size_t o_xy = 64, o_s = o_xy + (size_t)spec * 4, o_full = o_s + (size_t)spec * 8;
+  uint32_t* pin_xy = reinterpret_cast<uint32_t*>(pin + o_xy);
+  double* pin_s = reinterpret_cast<double*>(pin + o_s);
+  int32_t* pin_full = reinterpret_cast<int32_t*>(pin + o_full);
   const int y = blockIdx.x;
+  if (pin && y == 0 && threadIdx.x < 2) reinterpret_cast<unsigned long long*>(pin)[threadIdx.x] = header[threadIdx.x];
   int off = row_off[y], offa = row_off_all[y];
   for (int base = 0; base < w; base += 64) {
     const int x = base + (int)threadIdx.x;
@@ -488,9 +498,15 @@ __global__ void k_flag_row_write(const double* __restrict__ score, const uint8_t
     if (hit) {
       const int pos = off + __popcll(m & below);
       if (pos < cap) {
-        cand_xy[pos] = (uint32_t)x | ((uint32_t)y << 16) | (f == 2 ? 0x80000000u : 0u);
+        const uint32_t packed = (uint32_t)x | ((uint32_t)y << 16) | (f == 2 ? 0x80000000u : 0u);
+        cand_xy[pos] = packed;
         cand_s[pos] = s;
         cand_full[pos] = posa;
+        if (pin && pos < spec) {
+          pin_xy[pos] = packed;
+          pin_s[pos] = s;
+          pin_full[pos] = posa;
+        }
       }
     }
     off += __popcll(m);
@@ -619,7 +635,7 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   if (rc) return rc;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   prof_begin(c, KID_SHI_FIXPOINT);  // init + dense sweeps + work-list sweeps + tail + compaction
-  k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag);
+  k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag, c->wl[2].as<int>(), SHI_LIST_SWEEPS + 2);
   // Sweep 1 over all pixels (LDS tiles), then a fixed number of work-list sweeps.  The fixpoint is normally
   // reached after ~30 sweeps; later sweeps see an empty list and cost ~2 us, and stopping before the
   // fixpoint is always safe (undecided pixels simply travel to the host).
@@ -633,7 +649,6 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
     uint32_t* list0 = c->wl[0].as<uint32_t>();
     uint32_t* list1 = c->wl[1].as<uint32_t>();
     int* counts = c->wl[2].as<int>();
-    SFMX_HIP(c, hipMemsetAsync(counts, 0, (SHI_LIST_SWEEPS + 2) * sizeof(int), c->stream));
     k_shi_list_build<<<(npx + 255) / 256, 256, 0, c->stream>>>(d_flag, npx, list0, counts);
     for (int k = 0; k < SHI_LIST_SWEEPS; ++k)   // sparse phase: work-list sweeps
       k_shi_list_sweep<<<k < 3 ? 1024 : 256, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_flag, c->wl[3].as<int8_t>(), c->wl_ntaps,
@@ -648,19 +663,13 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   int* d_tot = reinterpret_cast<int*>(c->d[1].as<char>() + 8);
   k_row_scan<<<1, 64, 0, c->stream>>>(d_rows, p->h, d_tot);
   k_row_scan<<<1, 64, 0, c->stream>>>(d_rows_all, p->h, d_tot + 1);
+  // the 16-byte header plus the first SPEC survivors (there are ~1.5-2 k per VGA frame) go straight into pinned memory;
+  // a download happens only if there are more
+  const int SPEC = cap < SHI_SPEC ? cap : SHI_SPEC;
   k_flag_row_write<<<p->h, 64, 0, c->stream>>>(c->d[0].as<double>(), d_flag, p->w, d_rows, d_rows_all, cap, d_xy, c->d[4].as<double>(), d_full,
-                                          c->d[6].as<double2>());
+                                          c->d[6].as<double2>(), c->d[1].as<unsigned long long>(), c->h[2].as<char>(), SPEC);
   prof_end(c);
   SFMX_HIP(c, hipGetLastError());
-  // the 16-byte header plus a speculative download of the first SPEC survivors (there are ~1.5-2 k per
-  // VGA frame) through pinned memory; a second trip happens only if there are more
-  const int SPEC = cap < SHI_SPEC ? cap : SHI_SPEC;
-  const size_t o_xy = 64, o_s = o_xy + (size_t)SPEC * 4, o_full = o_s + (size_t)SPEC * 8;
-  char* pin = c->h[2].as<char>();
-  SFMX_HIP(c, hipMemcpyAsync(pin, c->d[1].p, 16, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(pin + o_xy, d_xy, (size_t)SPEC * 4, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(pin + o_s, c->d[4].p, (size_t)SPEC * 8, hipMemcpyDeviceToHost, c->stream));
-  SFMX_HIP(c, hipMemcpyAsync(pin + o_full, d_full, (size_t)SPEC * 4, hipMemcpyDeviceToHost, c->stream));
   return SFMX_OK;
 }
 

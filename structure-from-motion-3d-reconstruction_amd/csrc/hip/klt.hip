@@ -452,10 +452,7 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
     }
     const double fb = sfmx::hypot_glibc(px - p0x, py - p0y);
     keep[track] = (fb >= fb_thresh) ? 0 : 1;  // T:362: `if (fb >= thresh) continue;`
-    if (step_counter) {
-      atomicAdd(step_counter, (unsigned long long)steps);
-      if (slow_steps) atomicAdd(step_counter + 1, (unsigned long long)slow_steps);
-    }
+    if (step_counter) step_counter[track] = (unsigned long long)steps | ((unsigned long long)slow_steps << 32);  // summed by the host
     if (STAMP && stamps) {
       for (int k = 0; k < 6; k++) stamps[8 * track + k] = tph[k];
       stamps[8 * track + 6] = steps;
@@ -479,18 +476,15 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   SFMX_REQUIRE(c, xy_in != nullptr);
   const size_t nb = (size_t)n * 16;
   c->resident_points = 0;
-  // one device slab: [xy_in nb][fwd nb][back nb][steps 8][keep n]; one pinned slab for the upload and one
-  // for the download, so a call costs two DMA transfers and one host synchronisation
-  // device slab [xy_in nb][steps 8 (+8 pad)][fwd nb][back nb][keep n]: the upload covers the inputs and the zeroed
-  // step counter, the download everything behind it
-  const size_t o_steps = nb, o_fwd = nb + 16, o_back = o_fwd + nb, o_keep = o_back + nb, dev_bytes = o_keep + (size_t)n;
-  SFMX_HIP(c, c->d[0].ensure(dev_bytes + 64));
-  SFMX_HIP(c, c->h[0].ensure(nb + 16));
-  SFMX_HIP(c, c->h[1].ensure(dev_bytes - nb));
-  char* dbase = c->d[0].as<char>();
+  // No device slab and no DMA: the kernel reads the track positions straight out of pinned host memory (16 bytes per
+  // wavefront) and writes fwd | back | per-track step counts | keep into a second pinned slab (one small posted write per
+  // result and wavefront); the stream synchronisation below is the only wait.  The two copy kernels this replaces cost more
+  // than the transfers themselves: ~10 us each plus their dispatch gaps, per call.
+  const size_t o_fwd = 0, o_back = nb, o_steps = 2 * nb, o_keep = o_steps + (size_t)n * 8, out_bytes = o_keep + (size_t)n;
+  SFMX_HIP(c, c->h[0].ensure(nb));
+  SFMX_HIP(c, c->h[1].ensure(out_bytes));
   memcpy(c->h[0].p, xy_in, nb);
-  memset(c->h[0].as<char>() + nb, 0, 16);
-  SFMX_HIP(c, hipMemcpyAsync(dbase, c->h[0].p, nb + 16, hipMemcpyHostToDevice, c->stream));
+  char* dbase = c->h[1].as<char>();
   const int r = cfg->win_radius;
   KernelTimer t(c);
   t.start();
@@ -503,7 +497,7 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
     SFMX_HIP(c, hipMemsetAsync(d_stamps, 0, (size_t)n * 64, c->stream));
   }
 #define KLT_ARGS                                                                                                                          \
-  make_desc(pa), make_desc(pb), reinterpret_cast<double*>(dbase), n, cfg->levels, cfg->iters, cfg->fb_thresh,                             \
+  make_desc(pa), make_desc(pb), c->h[0].as<double>(), n, cfg->levels, cfg->iters, cfg->fb_thresh,                                         \
       reinterpret_cast<double*>(dbase + o_fwd), reinterpret_cast<double*>(dbase + o_back), reinterpret_cast<uint8_t*>(dbase + o_keep),  \
       reinterpret_cast<unsigned long long*>(dbase + o_steps), d_stamps
 #define KLT_LAUNCH(RR)                                                                              \
@@ -525,16 +519,18 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   prof_end(c);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
-  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, dbase + o_steps, dev_bytes - nb, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   t.collect();
-  const char* hp = c->h[1].as<char>();  // [steps 16][fwd nb][back nb][keep n]
-  unsigned long long steps = 0;
-  memcpy(&steps, hp, 8);
-  memcpy(&c->klt_slow_steps, hp + 8, 8);
-  memcpy(xy_fwd, hp + 16, nb);
-  if (xy_back) memcpy(xy_back, hp + 16 + nb, nb);
-  memcpy(keep, hp + 16 + 2 * nb, (size_t)n);
+  const char* hp = dbase;  // [fwd nb][back nb][steps n*8][keep n]
+  unsigned long long steps = 0, slow = 0;
+  {
+    const unsigned long long* ps = reinterpret_cast<const unsigned long long*>(hp + o_steps);
+    for (int i = 0; i < n; i++) { steps += ps[i] & 0xffffffffull; slow += ps[i] >> 32; }
+  }
+  c->klt_slow_steps = slow;
+  memcpy(xy_fwd, hp + o_fwd, nb);
+  if (xy_back) memcpy(xy_back, hp + o_back, nb);
+  memcpy(keep, hp + o_keep, (size_t)n);
   if (n_steps_out) *n_steps_out = steps;
   if (stamps_on) {  // per-phase s_memtime ticks per lk_step: track 0, the mean over all tracks, and the slowest track
     std::vector<unsigned long long> st((size_t)n * 8);

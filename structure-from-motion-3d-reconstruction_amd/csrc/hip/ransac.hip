@@ -379,7 +379,8 @@ __device__ __forceinline__ double sampson_eval(double e0, double e1, double e2, 
 // The reference's own count therefore lies in [counts[1], counts[2]].
 __global__ __launch_bounds__(SC_THREADS) void k_score(const double* __restrict__ xi, const double* __restrict__ xj, int n,
                                                       const double* __restrict__ E, const double* __restrict__ cond, int H, double thr,
-                                                      double kfac, int32_t* __restrict__ counts) {
+                                                      double kfac, int32_t* __restrict__ counts, double* __restrict__ cond_copy) {
+  // counts / cond_copy may point into pinned HOST memory: the few posted writes per workgroup replace a DMA copy
   const int h0 = blockIdx.x * SC_HB;
   const int tid = threadIdx.x;
   // one packed counter per hypothesis: bits 0..19 mid, 20..39 lo, 40..59 hi (n < 2^20 is checked by the host)
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_score(const double* __restrict__
     counts[h0 + tid] = (int32_t)(v & 0xfffffull);
     counts[H + h0 + tid] = (int32_t)((v >> 20) & 0xfffffull);
     counts[2 * H + h0 + tid] = (int32_t)((v >> 40) & 0xfffffull);
+    if (cond_copy) cond_copy[h0 + tid] = cond[h0 + tid];
   }
 }
 
@@ -482,7 +484,6 @@ int sfmx_ransac_score_ex(sfmx_ctx* c, const double* xi, const double* xj, int n,
   SFMX_HIP(c, c->d[1].ensure(patch_cap));
   SFMX_HIP(c, c->d[3].ensure((size_t)H * 72));
   SFMX_HIP(c, c->d[4].ensure(cnt_bytes + (size_t)H * 8));
-  SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
   SFMX_HIP(c, c->h[0].ensure(in_bytes + patch_cap));
   SFMX_HIP(c, c->h[1].ensure(cnt_bytes + (size_t)H * 8));
   char* hin = c->h[0].as<char>();
@@ -494,7 +495,6 @@ int sfmx_ransac_score_ex(sfmx_ctx* c, const double* xi, const double* xj, int n,
   const double* d_xi = c->d[0].as<double>();
   const double* d_xj = reinterpret_cast<const double*>(c->d[0].as<char>() + pb);
   const int32_t* d_idx = reinterpret_cast<const int32_t*>(c->d[0].as<char>() + 2 * pb);
-  int32_t* d_cnt = c->d[4].as<int32_t>();
   double* d_cond = reinterpret_cast<double*>(c->d[4].as<char>() + cnt_bytes);
   double* d_E = c->d[3].as<double>();
   // S >= 1 + |x| + |y| over all points of both images (k_score's band, see there)
@@ -528,14 +528,14 @@ int sfmx_ransac_score_ex(sfmx_ctx* c, const double* xi, const double* xj, int n,
     const int m = (int)exact_it.size();
     k_patch_E<<<(m * 9 + 255) / 256, 256, 0, c->stream>>>(d_E, d_cond, c->d[1].as<int32_t>(), d_rows, m);
   }
-  SFMX_PROF(c, KID_SCORE, (k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, d_E, d_cond, H, thr, kfac, d_cnt)));
+  // counts and a copy of the conditioning estimates go straight into the pinned result slab (zero-copy writes)
+  int32_t* h_cnt = c->h[1].as<int32_t>();
+  double* h_cond = reinterpret_cast<double*>(c->h[1].as<char>() + cnt_bytes);
+  SFMX_PROF(c, KID_SCORE, (k_score<<<(H + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, d_E, d_cond, H, thr, kfac, h_cnt, h_cond)));
   t.stop();
   SFMX_HIP(c, hipGetLastError());
-  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, c->d[4].p, cnt_bytes + (size_t)H * 8, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   t.collect();
-  int32_t* h_cnt = c->h[1].as<int32_t>();
-  const double* h_cond = reinterpret_cast<const double*>(c->h[1].as<char>() + cnt_bytes);
   std::vector<uint8_t> exact((size_t)H, 0);
   for (int32_t h : exact_it) exact[(size_t)h] = 1;
   // ---- ill-conditioned device hypotheses (eigenvalue gap, rank-2 gap, nearly tied pivot): second, rare round --
@@ -549,15 +549,12 @@ int sfmx_ransac_score_ex(sfmx_ctx* c, const double* xi, const double* xj, int n,
     const double* d_rows = nullptr;
     const int rc = upload_exact(redo, &d_rows);
     if (rc != SFMX_OK) return rc;
-    SFMX_HIP(c, c->d[2].ensure((size_t)m * 12 + 64));
     SFMX_HIP(c, c->h[2].ensure((size_t)m * 12 + 64));
-    int32_t* d_cnt2 = c->d[2].as<int32_t>();
+    int32_t* c2 = c->h[2].as<int32_t>();
     k_patch_E<<<(m * 9 + 255) / 256, 256, 0, c->stream>>>(d_E, d_cond, c->d[1].as<int32_t>(), d_rows, m);
-    k_score<<<(m + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, d_rows, d_rows + (size_t)9 * m, m, thr, kfac, d_cnt2);
+    k_score<<<(m + SC_HB - 1) / SC_HB, SC_THREADS, 0, c->stream>>>(d_xi, d_xj, n, d_rows, d_rows + (size_t)9 * m, m, thr, kfac, c2, nullptr);
     SFMX_HIP(c, hipGetLastError());
-    SFMX_HIP(c, hipMemcpyAsync(c->h[2].p, d_cnt2, (size_t)m * 12, hipMemcpyDeviceToHost, c->stream));
     SFMX_HIP(c, hipStreamSynchronize(c->stream));
-    const int32_t* c2 = c->h[2].as<int32_t>();
     for (int k = 0; k < m; k++) {
       h_cnt[redo[(size_t)k]] = c2[k];
       exact[(size_t)redo[(size_t)k]] = 1;
@@ -596,7 +593,6 @@ int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, co
                       int32_t* count_out) {
   SFMX_REQUIRE(c, c && E9in && mask_out && n > 0 && ((xi && xj) || (!xi && !xj && c->resident_points == n)));
   const size_t pb = (size_t)n * 16;
-  SFMX_HIP(c, c->d[5].ensure((size_t)n + 128));
   SFMX_HIP(c, c->h[2].ensure((size_t)n + 64));
   if (xi) {  // same layout as sfmx_ransac_score leaves behind: [xi pb][xj pb]
     SFMX_HIP(c, c->d[0].ensure(2 * pb));
@@ -608,10 +604,8 @@ int sfmx_sampson_mask(sfmx_ctx* c, const double* xi, const double* xj, int n, co
   const double* d_xj = reinterpret_cast<const double*>(c->d[0].as<char>() + pb);
   E9 E;
   memcpy(E.e, E9in, 72);
-  uint8_t* d_mask = c->d[5].as<uint8_t>() + 64;
-  k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(d_xi, d_xj, n, E, thr, d_mask);
+  k_sampson_mask<<<(n + 255) / 256, 256, 0, c->stream>>>(d_xi, d_xj, n, E, thr, c->h[2].as<uint8_t>());  // written into pinned memory
   SFMX_HIP(c, hipGetLastError());
-  SFMX_HIP(c, hipMemcpyAsync(c->h[2].p, d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   SFMX_HIP(c, hipStreamSynchronize(c->stream));
   memcpy(mask_out, c->h[2].p, (size_t)n);
   int32_t cnt = 0;
