@@ -207,7 +207,11 @@ template <int PTS, int NT>
 __global__ __launch_bounds__(NT) void k_ba_points(int W, int P, int MS, const double* __restrict__ poses, const double* __restrict__ X,
                                                   const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
                                                   const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
-                                                  double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C) {
+                                                  double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C,
+                                                  int wave_prio) {
+  // the BA iterations are the longest dependent chain of a keyframe: their waves go first where they share a SIMD with
+  // the bulk kernels of the other lanes (KLT, hypotheses, corner sweeps)
+  if (wave_prio) __builtin_amdgcn_s_setprio(3);
   __shared__ double sp[BA_MAX_W * 12];
   const int tid = threadIdx.x;
   for (int i = tid; i < W * 12; i += NT) sp[i] = poses[i];
@@ -614,7 +618,8 @@ template <int BAR_TP, int SOLVE_N>
 __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
                                                    double* __restrict__ S, double* __restrict__ b,
                                                    unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
-                                                   unsigned long long seq) {
+                                                   unsigned long long seq, int wave_prio) {
+  if (wave_prio) __builtin_amdgcn_s_setprio(3);  // see k_ba_points
   constexpr int BAR_K = BAR_TP / BAR_Q;  // rows per thread and tile
   constexpr int TILE_DOUBLES = 2 * BAR_NBUF * BAR_TP * BAR_COLS;
   constexpr int SOLVE_DOUBLES = SOLVE_N > 0 ? SOLVE_N * ((SOLVE_N + 1) | 1) + SOLVE_N + 2 : 0;
@@ -1097,27 +1102,28 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   if (!zero_copy_poses) SFMX_HIP(c, hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
   const int D = 6 * q->W;
   t.start();
+  static const int wave_prio = getenv("SFMX_BA_NO_WAVE_PRIO") ? 0 : 1;
   static const char* expand_env = getenv("SFMX_BA_EXPAND");  // "split" / "merged": A/B and tests
   const bool merged = expand_env ? expand_env[0] == 'm' : q->P <= BA_MERGED_EXPAND_MAX_P;
   if (merged) {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<BA_PTS, 256><<<(q->P + BA_PTS - 1) / BA_PTS, 256, 0, c->stream>>>(
-                                    q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib)));
+                                    q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
   } else {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<64, 64><<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx,
-                                                                                         fy, cx, cy, huber, q->rec, q->slot_of, nullptr)));
+                                                                                         fy, cx, cy, huber, q->rec, q->slot_of, nullptr, wave_prio)));
     const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
     SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
   }
   const int nwg = (D * D + D + BAR_COLS - 1) / BAR_COLS;
   if (fused_solve && q->W == 6) {
     SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                              q->ticket, q->work, host_out, seq)));
+                                                                              q->ticket, q->work, host_out, seq, wave_prio)));
   } else if (fused_solve && q->W == 10) {
     SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 60><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                              q->ticket, q->work, host_out, seq)));
+                                                                              q->ticket, q->work, host_out, seq, wave_prio)));
   } else {
     SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                             nullptr, nullptr, nullptr, 0)));
+                                                                             nullptr, nullptr, nullptr, 0, wave_prio)));
   }
   t.stop();
   SFMX_HIP(c, hipGetLastError());
