@@ -195,7 +195,11 @@ template <int r, bool STAMP>
 __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
                                                   int iters, double fb_thresh, double* __restrict__ xy_fwd,
                                                   double* __restrict__ xy_back, uint8_t* __restrict__ keep,
-                                                  unsigned long long* __restrict__ step_counter, unsigned long long* __restrict__ stamps) {
+                                                  unsigned long long* __restrict__ step_counter, unsigned long long* __restrict__ stamps,
+                                                  int wave_prio) {
+  // wave priority (s_setprio, 0..3): above the bulk kernels of the other lanes, below the BA chain (3)
+  if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2);
   using L = KltLds<r>;
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
   auto stamp = [&](int k) {
@@ -489,6 +493,7 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   KernelTimer t(c);
   t.start();
   prof_begin(c, KID_KLT);
+  static const int klt_prio = getenv("SFMX_KLT_WAVE_PRIO") ? atoi(getenv("SFMX_KLT_WAVE_PRIO")) : 0;
   static const bool stamps_on = getenv("SFMX_KLT_STAMPS") != nullptr;  // diagnostic build of the kernel, see k_klt_track
   unsigned long long* d_stamps = nullptr;
   if (stamps_on) {
@@ -499,7 +504,7 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
 #define KLT_ARGS                                                                                                                          \
   make_desc(pa), make_desc(pb), c->h[0].as<double>(), n, cfg->levels, cfg->iters, cfg->fb_thresh,                                         \
       reinterpret_cast<double*>(dbase + o_fwd), reinterpret_cast<double*>(dbase + o_back), reinterpret_cast<uint8_t*>(dbase + o_keep),  \
-      reinterpret_cast<unsigned long long*>(dbase + o_steps), d_stamps
+      reinterpret_cast<unsigned long long*>(dbase + o_steps), d_stamps, klt_prio
 #define KLT_LAUNCH(RR)                                                                              \
   do {                                                                                              \
     if (stamps_on && RR == 5) k_klt_track<5, true><<<n, 64, klt_lds_bytes<5>(), c->stream>>>(KLT_ARGS); \
