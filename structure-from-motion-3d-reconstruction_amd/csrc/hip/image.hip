@@ -621,7 +621,8 @@ void sfmx_release_graphs(sfmx_ctx* c) {
 #ifndef SHI_LIST_SWEEPS
 #define SHI_LIST_SWEEPS 8
 #endif
-#define SHI_TAIL_SWEEPS 40
+#define SHI_TAIL_SWEEPS 0  // the one-workgroup tail (<= 40 sweeps for the last few hundred pixels) cost 160 us of device time per image to spare the
+                           // host resolver a few hundred survivors: with the device as the bound of the pipeline it is off (SFMX_SHI_SWEEPS=5,8,40)
 
 static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int min_dist, int cap) {
   unsigned long long* d_max = c->d[1].as<unsigned long long>();
@@ -643,20 +644,32 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
     const int r = min_dist - 1;
     const size_t shm = (size_t)(SR_TX + 2 * r) * (SR_TY + 2 * r) * 9 + 16;
     dim3 gt((p->w + SR_TX - 1) / SR_TX, (p->h + SR_TY - 1) / SR_TY);
-    for (int k = 0; k < SHI_TILED_SWEEPS; ++k)  // dense phase: LDS-tiled sweeps over all pixels
+    // SFMX_SHI_SWEEPS="tiled,list,tail" overrides the schedule (A/B; any schedule is exact: undecided pixels travel to the host)
+    static int tiled_sweeps = SHI_TILED_SWEEPS, list_sweeps = SHI_LIST_SWEEPS, tail_sweeps = SHI_TAIL_SWEEPS;
+    static const bool parsed = [] {
+      if (const char* e = getenv("SFMX_SHI_SWEEPS")) {
+        int a = -1, b = -1, t = -1;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &t) == 3 && a >= 1 && a <= 64 && b >= 0 && b <= SHI_LIST_SWEEPS && t >= 0 && t <= 1000) {
+          tiled_sweeps = a; list_sweeps = b; tail_sweeps = t;
+        }
+      }
+      return true;
+    }();
+    (void)parsed;
+    for (int k = 0; k < tiled_sweeps; ++k)  // dense phase: LDS-tiled sweeps over all pixels
       k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
     const int npx = p->w * p->h;
     uint32_t* list0 = c->wl[0].as<uint32_t>();
     uint32_t* list1 = c->wl[1].as<uint32_t>();
     int* counts = c->wl[2].as<int>();
-    k_shi_list_build<<<(npx + 255) / 256, 256, 0, c->stream>>>(d_flag, npx, list0, counts);
-    for (int k = 0; k < SHI_LIST_SWEEPS; ++k)   // sparse phase: work-list sweeps
+    if (list_sweeps > 0 || tail_sweeps > 0) k_shi_list_build<<<(npx + 255) / 256, 256, 0, c->stream>>>(d_flag, npx, list0, counts);
+    for (int k = 0; k < list_sweeps; ++k)   // sparse phase: work-list sweeps
       k_shi_list_sweep<<<k < 3 ? 1024 : 256, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_flag, c->wl[3].as<int8_t>(), c->wl_ntaps,
                                                                   (k & 1) ? list1 : list0, counts + k, (k & 1) ? list0 : list1, counts + k + 1);
     // tail: the remaining sweeps inside one workgroup
-    k_shi_list_tail<<<1, 1024, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_flag, c->wl[3].as<int8_t>(), c->wl_ntaps,
-                                               (SHI_LIST_SWEEPS & 1) ? list1 : list0, (SHI_LIST_SWEEPS & 1) ? list0 : list1,
-                                               counts + SHI_LIST_SWEEPS, SHI_TAIL_SWEEPS);
+    if (tail_sweeps > 0)
+      k_shi_list_tail<<<1, 1024, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_flag, c->wl[3].as<int8_t>(), c->wl_ntaps,
+                                                 (list_sweeps & 1) ? list1 : list0, (list_sweeps & 1) ? list0 : list1, counts + list_sweeps, tail_sweeps);
   }
   k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_rows_all);
   // header in d[1]: [0] max score bits (8 B) | [8] #survivors (4 B) | [12] #candidates (4 B)
