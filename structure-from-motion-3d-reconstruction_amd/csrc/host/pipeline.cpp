@@ -779,11 +779,11 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
 // ------------------------------------------------------------------------------------------ map
 int MapState::add(int tid, V3 Xw) {
   const int pid = next_pid++;
-  MapPoint mp;
+  MapPoint mp(pts.get_allocator().arena);
   mp.pid = pid;
   mp.tid = tid;
   mp.Xw = Xw;
-  pts.emplace(pid, mp);
+  pts.emplace(pid, std::move(mp));
   tid2pid.emplace(tid, pid);
   return pid;
 }

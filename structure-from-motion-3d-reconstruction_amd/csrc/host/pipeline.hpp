@@ -340,7 +340,8 @@ struct Keyframe {
 struct MapPoint {
   int pid = 0, tid = 0;
   V3 Xw;
-  std::vector<std::pair<int, V2>> obs;
+  std::vector<std::pair<int, V2>, ArenaAlloc<std::pair<int, V2>>> obs;  // in the map's arena (null arena: plain new/delete)
+  explicit MapPoint(Arena* a = nullptr) : obs(ArenaAlloc<std::pair<int, V2>>(a)) {}
 };
 struct MapState {
   int next_pid = 0;
