@@ -92,7 +92,81 @@ __device__ __forceinline__ void ba_accumulate_slot(double* __restrict__ A, const
     }
 }
 
-// per-point records (T:894-1047) of point p: slots in first-observation order, Hxx | bx | Hxp, then G = Hxp Hpp^-1 and G*bp
+// One observation of a point (T:921-1009): the slot record A (Hxx | bx | Hxp) and the twelve terms wgt*s it adds to Hpp (9)
+// and bp (3).  false: the point is on or behind the camera plane (T:933; NaN passes, as in the reference) -- the slot
+// exists (T:925-930) but stays zero and nothing is added to Hpp / bp.
+template <bool FRESH>
+__device__ __forceinline__ bool ba_observation(double* __restrict__ A, const double* __restrict__ R, double Xx, double Xy, double Xz, double u,
+                                               double v, double fx, double fy, double cx, double cy, double huber, double* __restrict__ term) {
+  const double Xcx = (R[0] * Xx + R[1] * Xy + R[2] * Xz) + R[9];
+  const double Xcy = (R[3] * Xx + R[4] * Xy + R[5] * Xz) + R[10];
+  const double Xcz = (R[6] * Xx + R[7] * Xy + R[8] * Xz) + R[11];
+  if (Xcz <= 1e-6) {
+    if (FRESH)
+      for (int k = 0; k < 60; k++) A[k] = 0.0;
+    return false;
+  }
+  const double qx = Xcx / Xcz, qy = Xcy / Xcz;
+  const double rx = u - (fx * qx + cx);
+  const double ry = v - (fy * qy + cy);
+  const double rn = sfmx::hypot_glibc(rx, ry);
+  const double wgt = (rn <= huber) ? 1.0 : huber / (rn + 1e-12);
+  const double iz = 1.0 / Xcz, iz2 = iz * iz;
+  double Jq[6];
+  Jq[0] = fx * iz; Jq[1] = 0.0; Jq[2] = -fx * Xcx * iz2;
+  Jq[3] = 0.0; Jq[4] = fy * iz; Jq[5] = -fy * Xcy * iz2;
+  double Jp[6], Jr[6];
+#pragma unroll
+  for (int row = 0; row < 2; ++row)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double a0 = Jq[row * 3 + 0] * R[c], a1 = Jq[row * 3 + 1] * R[3 + c], a2 = Jq[row * 3 + 2] * R[6 + c];
+      Jp[row * 3 + c] = a0 + a1 + a2;
+    }
+  const double Xm[9] = {0.0, -Xcz, Xcy, Xcz, 0.0, -Xcx, -Xcy, Xcx, 0.0};
+#pragma unroll
+  for (int row = 0; row < 2; ++row)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double a0 = -Jq[row * 3 + 0] * Xm[c], a1 = -Jq[row * 3 + 1] * Xm[3 + c], a2 = -Jq[row * 3 + 2] * Xm[6 + c];
+      Jr[row * 3 + c] = a0 + a1 + a2;
+    }
+  const double Jx[12] = {Jr[0], Jr[1], Jr[2], Jq[0], Jq[1], Jq[2], Jr[3], Jr[4], Jr[5], Jq[3], Jq[4], Jq[5]};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double s = 0.0;
+      s += Jp[a] * Jp[c];
+      s += Jp[3 + a] * Jp[3 + c];
+      term[a * 3 + c] = wgt * s;
+    }
+    double sb = 0.0;
+    sb += Jp[a] * rx;
+    sb += Jp[3 + a] * ry;
+    term[9 + a] = wgt * sb;
+  }
+  ba_accumulate_slot<FRESH>(A, Jx, Jp, wgt, rx, ry);
+  return true;
+}
+// G = Hxp Hpp^-1 and G*bp of one slot (T:1020-1041)
+__device__ __forceinline__ void ba_slot_gain(double* __restrict__ A, const double* __restrict__ iH, const double* __restrict__ bp) {
+  const double* Hxp = A + 42;
+  double* G = A + 60;
+  double* gb = A + 78;
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const double h0 = Hxp[r * 3 + 0], h1 = Hxp[r * 3 + 1], h2 = Hxp[r * 3 + 2];
+    const double g0 = h0 * iH[0] + h1 * iH[3] + h2 * iH[6];
+    const double g1 = h0 * iH[1] + h1 * iH[4] + h2 * iH[7];
+    const double g2 = h0 * iH[2] + h1 * iH[5] + h2 * iH[8];
+    G[r * 3 + 0] = g0; G[r * 3 + 1] = g1; G[r * 3 + 2] = g2;
+    gb[r] = g0 * bp[0] + g1 * bp[1] + g2 * bp[2];
+  }
+}
+
+// per-point records (T:894-1047) of point p by ONE lane: slots in first-observation order, Hxx | bx | Hxp, then G = Hxp Hpp^-1
+// and G*bp
 __device__ __forceinline__ void ba_point_record(int p, int W, int MS, const double* __restrict__ sp, const double* __restrict__ X,
                                                 const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
                                                 const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy, double huber,
@@ -115,78 +189,101 @@ __device__ __forceinline__ void ba_point_record(int p, int W, int MS, const doub
       so[li] = (int8_t)ai;
     }
     double* A = prec + (size_t)ai * BA_SLOT;
-    const double* R = sp + 12 * li;
-    const double Xcx = (R[0] * Xx + R[1] * Xy + R[2] * Xz) + R[9];
-    const double Xcy = (R[3] * Xx + R[4] * Xy + R[5] * Xz) + R[10];
-    const double Xcz = (R[6] * Xx + R[7] * Xy + R[8] * Xz) + R[11];
-    if (Xcz <= 1e-6) {  // T:933 (NaN passes, as in the reference); the slot exists (T:925-930) but stays zero
-      if (fresh)
-        for (int k = 0; k < 60; k++) A[k] = 0.0;
-      continue;
+    double term[12];
+    const bool adds = fresh ? ba_observation<true>(A, sp + 12 * li, Xx, Xy, Xz, obs_uv[2 * o], obs_uv[2 * o + 1], fx, fy, cx, cy, huber, term)
+                            : ba_observation<false>(A, sp + 12 * li, Xx, Xy, Xz, obs_uv[2 * o], obs_uv[2 * o + 1], fx, fy, cx, cy, huber, term);
+    if (adds) {
+#pragma unroll
+      for (int e = 0; e < 9; e++) Hpp[e] += term[e];
+#pragma unroll
+      for (int a = 0; a < 3; a++) bp[a] += term[9 + a];
     }
-    const double qx = Xcx / Xcz, qy = Xcy / Xcz;
-    const double rx = obs_uv[2 * o] - (fx * qx + cx);
-    const double ry = obs_uv[2 * o + 1] - (fy * qy + cy);
-    const double rn = sfmx::hypot_glibc(rx, ry);
-    const double wgt = (rn <= huber) ? 1.0 : huber / (rn + 1e-12);
-    const double iz = 1.0 / Xcz, iz2 = iz * iz;
-    double Jq[6];
-    Jq[0] = fx * iz; Jq[1] = 0.0; Jq[2] = -fx * Xcx * iz2;
-    Jq[3] = 0.0; Jq[4] = fy * iz; Jq[5] = -fy * Xcy * iz2;
-    double Jp[6], Jr[6];
-#pragma unroll
-    for (int row = 0; row < 2; ++row)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double a0 = Jq[row * 3 + 0] * R[c], a1 = Jq[row * 3 + 1] * R[3 + c], a2 = Jq[row * 3 + 2] * R[6 + c];
-        Jp[row * 3 + c] = a0 + a1 + a2;
-      }
-    const double Xm[9] = {0.0, -Xcz, Xcy, Xcz, 0.0, -Xcx, -Xcy, Xcx, 0.0};
-#pragma unroll
-    for (int row = 0; row < 2; ++row)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const double a0 = -Jq[row * 3 + 0] * Xm[c], a1 = -Jq[row * 3 + 1] * Xm[3 + c], a2 = -Jq[row * 3 + 2] * Xm[6 + c];
-        Jr[row * 3 + c] = a0 + a1 + a2;
-      }
-    const double Jx[12] = {Jr[0], Jr[1], Jr[2], Jq[0], Jq[1], Jq[2], Jr[3], Jr[4], Jr[5], Jq[3], Jq[4], Jq[5]};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        double s = 0.0;
-        s += Jp[a] * Jp[c];
-        s += Jp[3 + a] * Jp[3 + c];
-        Hpp[a * 3 + c] += wgt * s;
-      }
-      double sb = 0.0;
-      sb += Jp[a] * rx;
-      sb += Jp[3 + a] * ry;
-      bp[a] += wgt * sb;
-    }
-    if (fresh) ba_accumulate_slot<true>(A, Jx, Jp, wgt, rx, ry);
-    else ba_accumulate_slot<false>(A, Jx, Jp, wgt, rx, ry);
   }
   double iH[9];
   if (!inv3_ref(Hpp, iH)) {  // T:1012: the point contributes nothing at all
     for (int i = 0; i < W; i++) so[i] = -1;
     return;
   }
-  for (int k = 0; k < na; k++) {
-    double* A = prec + (size_t)k * BA_SLOT;
-    const double* Hxp = A + 42;
-    double* G = A + 60;
-    double* gb = A + 78;
-#pragma unroll
-    for (int r = 0; r < 6; r++) {
-      const double h0 = Hxp[r * 3 + 0], h1 = Hxp[r * 3 + 1], h2 = Hxp[r * 3 + 2];
-      const double g0 = h0 * iH[0] + h1 * iH[3] + h2 * iH[6];
-      const double g1 = h0 * iH[1] + h1 * iH[4] + h2 * iH[7];
-      const double g2 = h0 * iH[2] + h1 * iH[5] + h2 * iH[8];
-      G[r * 3 + 0] = g0; G[r * 3 + 1] = g1; G[r * 3 + 2] = g2;
-      gb[r] = g0 * bp[0] + g1 * bp[1] + g2 * bp[2];
+  for (int k = 0; k < na; k++) ba_slot_gain(prec + (size_t)k * BA_SLOT, iH, bp);
+}
+
+// The same records for PTS points by 16 * PTS lanes of one wave (PTS <= 4): the observations of a point are independent
+// up to the ordered sums Hpp / bp, which 12 lanes per point run over the per-observation terms in observation order --
+// the reference's `+=` sequence.  A pose that observes a point twice (read-modify-write of its slot) sends that point
+// down the one-lane path.  Must be called by all threads of the workgroup (barriers).
+template <int PTS>
+__device__ __forceinline__ void ba_point_records_wave(int p0, int P, int W, int MS, const double* __restrict__ sp, const double* __restrict__ X,
+                                                      const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
+                                                      const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy, double huber,
+                                                      double* __restrict__ rec, int8_t* __restrict__ slot_of) {
+  static_assert(PTS * BA_MAX_OBS <= 64, "one wave");
+  __shared__ double s_term[PTS][BA_MAX_OBS][12];
+  __shared__ double s_H[PTS][12], s_iH[PTS][9];
+  __shared__ int s_n[PTS], s_na[PTS], s_par[PTS], s_ok[PTS];  // s_par: the point takes the lane-parallel path
+  __shared__ int8_t s_slot[PTS][BA_MAX_OBS], s_adds[PTS][BA_MAX_OBS];
+  const int tid = threadIdx.x;
+  if (tid < PTS) {  // ---- slots in first-observation order (integer work only)
+    const int p = p0 + tid;
+    int n = 0, na = 0, par = 0;
+    if (p < P) {
+      int8_t* so = slot_of + (size_t)p * W;
+      for (int i = 0; i < W; i++) so[i] = -1;
+      const int o0 = obs_ptr[p], cnt = obs_ptr[p + 1] - o0;
+      if (cnt <= BA_MAX_OBS) {  // T:915-918
+        n = cnt;
+        par = 1;
+        for (int k = 0; k < cnt; k++) {
+          const int li = obs_li[o0 + k];
+          int sl = -1;
+          if (li >= 0 && li < W) {
+            if (so[li] < 0) { sl = na++; so[li] = (int8_t)sl; }
+            else par = 0;  // the same pose again
+          }
+          s_slot[tid][k] = (int8_t)sl;
+        }
+        if (!par) {
+          ba_point_record(p, W, MS, sp, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of);
+          n = 0;
+        }
+      }
     }
+    s_n[tid] = n; s_na[tid] = na; s_par[tid] = par;
   }
+  __syncthreads();
+  const int pt = tid / BA_MAX_OBS, k = tid % BA_MAX_OBS;
+  if (tid < PTS * BA_MAX_OBS && k < s_n[pt]) {  // ---- one lane per observation
+    const int p = p0 + pt, sl = s_slot[pt][k];
+    bool adds = false;
+    if (sl >= 0) {
+      const int o = obs_ptr[p] + k;
+      adds = ba_observation<true>(rec + ((size_t)p * MS + sl) * BA_SLOT, sp + 12 * obs_li[o], X[3 * p], X[3 * p + 1], X[3 * p + 2], obs_uv[2 * o],
+                                  obs_uv[2 * o + 1], fx, fy, cx, cy, huber, s_term[pt][k]);
+    }
+    s_adds[pt][k] = adds ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid < PTS * 12) {  // ---- Hpp (9) and bp (3): the reference's += chain over the observations
+    const int q = tid / 12, e = tid % 12, n = s_n[q];
+    double acc = 0.0;
+    for (int kk = 0; kk < n; kk++)
+      if (s_adds[q][kk]) acc += s_term[q][kk][e];
+    s_H[q][e] = acc;
+  }
+  __syncthreads();
+  if (tid < PTS) {
+    int ok = 0;
+    if (s_n[tid] > 0 || (s_par[tid] && p0 + tid < P)) {
+      ok = inv3_ref(s_H[tid], s_iH[tid]) ? 1 : 0;
+      if (!ok && s_par[tid]) {  // T:1012: the point contributes nothing at all
+        int8_t* so = slot_of + (size_t)(p0 + tid) * W;
+        for (int i = 0; i < W; i++) so[i] = -1;
+      }
+    }
+    s_ok[tid] = ok && s_par[tid];
+  }
+  __syncthreads();
+  if (tid < PTS * BA_MAX_OBS && s_ok[pt] && k < s_na[pt])  // ---- one lane per slot
+    ba_slot_gain(rec + ((size_t)(p0 + pt) * MS + k) * BA_SLOT, s_iH[pt], s_H[pt] + 9);
 }
 
 __device__ __forceinline__ int ba_row_stride(int W) { return 36 * W * W + 36 * W + 12 * W; }
@@ -217,7 +314,11 @@ __global__ __launch_bounds__(NT) void k_ba_points(int W, int P, int MS, const do
   for (int i = tid; i < W * 12; i += NT) sp[i] = poses[i];
   __syncthreads();
   const int p0 = blockIdx.x * PTS;
-  if (tid < PTS && p0 + tid < P) ba_point_record(p0 + tid, W, MS, sp, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of);
+  if constexpr (PTS * BA_MAX_OBS <= 64 && NT >= 64) {
+    ba_point_records_wave<PTS>(p0, P, W, MS, sp, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of);
+  } else {
+    if (tid < PTS && p0 + tid < P) ba_point_record(p0 + tid, W, MS, sp, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of);
+  }
   if (C == nullptr) return;
   __syncthreads();  // the records and slot tables of this workgroup's points are visible to all its threads
   const int D = 6 * W, CS = ba_row_stride(W);

@@ -1142,6 +1142,8 @@ FrameFeeder::FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig&
     if (pc_) borrowed = &pc_->pyramid_ring(src.width(), src.height(), std::max(cfg.pyr_levels, extra_levels), ring_);
     tracker_ = std::make_unique<GpuTracker>(ctx_, cfg, src.width(), src.height(), extra_levels, clk_, ring_, hook, borrowed);
     tracker_->set_prefetcher(prefetch_);
+    if (prefetch_)  // the corners of the first frames are on their way before the tracker asks for them (T:330 at frame 0)
+      for (int a = 0; a <= prefetch_depth_ && a < n_frames_; ++a) prefetch_->request(a);
     if (threaded) th_ = std::thread([this] { run(); });
   } catch (...) {
     tracker_.reset();
@@ -1443,8 +1445,11 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   static const bool trace_phases = std::getenv("SFMX_TRACE_PHASES") != nullptr;
   auto phase = [&](const char* what) { if (trace_phases) std::fprintf(stderr, "phase %-22s %8.3f ms\n", what, since(t_all) * 1e3); };
   phase("setup done");
+  double t_par = 0, t_emit = 0, t_rel = 0, t_first = 0, t_loopjoin = 0;
   for (int fi = 0; fi < std::min(frames, src.count()); ++fi) {
+    const auto tlj = Clock::now();
     if (pending_loop.active && fi >= pending_loop.frame + 2) join_lane();  // its 'current' pyramid is about to be reused
+    t_loopjoin += since(tlj);
     const auto tm0 = Clock::now();
     FramePacket pkt = feeder.next();
     clk.feed_wait += since(tm0);
@@ -1467,6 +1472,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       last_kf_frame = fi;
       emit(fi);
       release_frames(fi);
+      t_first += since(tm0);
       continue;
     }
     const std::vector<V2>& p_i = step.prev_pts;
@@ -1476,6 +1482,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     if (pkt.rel.valid()) rel = pkt.rel.get();                                     // T:1739, started ahead on lane A
     else rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk, cfg.comm_ransac_a);
     clk.m_ransac += since(tm1);
+    const auto tp0 = Clock::now();
     int inliers = 0;
     double parallax = 0.0;
     if (rel) {
@@ -1495,6 +1502,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       else if (inliers < cfg.kf_min_inliers) make_kf = true;
       else make_kf = parallax >= cfg.kf_parallax_px;
     }
+    t_par += since(tp0);
     const auto tm2 = Clock::now();
     if (make_kf) {
       // Edges stay in keyframe order (lane C first).  BA(k-1) refined the poses the triangulation below reads, but
@@ -1645,9 +1653,14 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       }
     }
     clk.m_kf += since(tm2);
+    const auto te0 = Clock::now();
     emit(fi);
+    t_emit += since(te0);
+    const auto tr0 = Clock::now();
     release_frames(fi);
+    t_rel += since(tr0);
   }
+  if (trace_phases) std::fprintf(stderr, "loop parts: parallax %.3f emit %.3f release %.3f first-frame %.3f loop-join %.3f feed %.3f ransac %.3f kf %.3f ms\n", t_par * 1e3, t_emit * 1e3, t_rel * 1e3, t_first * 1e3, t_loopjoin * 1e3, clk.feed_wait * 1e3, clk.m_ransac * 1e3, clk.m_kf * 1e3);
   phase("frame loop done");
   join_lane();
   flush_edges();
