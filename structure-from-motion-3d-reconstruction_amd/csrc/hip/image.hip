@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_shi_init(const double* __restrict__ sco
 // Same decisions as scanning the whole disc per pixel (the first version: 450 LDS reads per undecided pixel, 56 us per
 // sweep over a VGA image), at a tenth of the LDS traffic.
 __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ state,
-                                                   int* __restrict__ changed) {
+                                                   int* __restrict__ changed, int inner) {
   extern __shared__ __align__(16) unsigned char sr_mem[];
   __shared__ int n_acc, n_sur;
   __shared__ unsigned short acc_idx[SR_MAXACC], sur_idx[256];
@@ -306,73 +306,96 @@ __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ sc
   __syncthreads();
   const int cy = ty + r, cx = tx + r;
   const double s = ts[cy * lw + cx];
-  const int nacc = n_acc;
-  const bool listed = nacc <= SR_MAXACC && r >= 1;  // otherwise: the plain scan of the whole disc
-  bool rejected = false, blocked = false;
-  if (mine == 1) {
-    if (listed) {
-      for (int k = 0; k < nacc; k++) {  // (R)
-        const int i = acc_idx[k];
-        const int ay = i / lw, ax = i - ay * lw;
-        const int dx = ax - cx, dy = ay - cy;
-        rejected |= (dx * dx + dy * dy < md2) && (ts[i] > s);
-      }
-      if (!rejected) {  // (A), direct neighbours first (all inside the disc: md >= 2)
+  uint8_t st_mine = mine;
+  bool wrote = false;
+  // `inner` sweeps on the staged tile: a decision taken in one sweep is visible (LDS state tile, accepted list) to the
+  // block's other pixels in the next, so dependency chains that stay inside the tile resolve within one launch and one
+  // staging.  Halo states stay at their snapshot, which is always safe.
+  for (int sweep = 0; sweep < inner; ++sweep) {
+    const int nacc = n_acc;
+    const bool listed = nacc <= SR_MAXACC && r >= 1;  // otherwise: the plain scan of the whole disc
+    bool rejected = false, blocked = false;
+    if (tid == 0) n_sur = 0;
+    __syncthreads();
+    if (st_mine == 1) {
+      if (listed) {
+        for (int k = 0; k < nacc; k++) {  // (R)
+          const int i = acc_idx[k];
+          const int ay = i / lw, ax = i - ay * lw;
+          const int dx = ax - cx, dy = ay - cy;
+          rejected |= (dx * dx + dy * dy < md2) && (ts[i] > s);
+        }
+        if (!rejected) {  // (A), direct neighbours first (all inside the disc: md >= 2)
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+          for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-          for (int dx = -1; dx <= 1; ++dx) {
-            if (dx == 0 && dy == 0) continue;
-            const uint8_t st = tq[(cy + dy) * lw + cx + dx];
-            blocked |= (st == 1 || st == 2) && (ts[(cy + dy) * lw + cx + dx] >= s);
+            for (int dx = -1; dx <= 1; ++dx) {
+              if (dx == 0 && dy == 0) continue;
+              const uint8_t st = tq[(cy + dy) * lw + cx + dx];
+              blocked |= (st == 1 || st == 2) && (ts[(cy + dy) * lw + cx + dx] >= s);
+            }
+          if (!blocked) {
+            const int k = atomicAdd(&n_sur, 1);
+            sur_idx[k] = (unsigned short)tid;
+            sur_blocked[tid] = 0;
           }
-        if (!blocked) {
-          const int k = atomicAdd(&n_sur, 1);
-          sur_idx[k] = (unsigned short)tid;
-          sur_blocked[tid] = 0;
+        }
+      } else {
+        for (int dy = -r; dy <= r && !rejected; ++dy) {
+          const int rem = md2 - dy * dy;  // dx*dx < rem
+          const double* rs = ts + (cy + dy) * lw + cx;
+          const uint8_t* rq = tq + (cy + dy) * lw + cx;
+          for (int dx = -r; dx <= r; ++dx) {
+            const uint8_t st = rq[dx];
+            const double sq = rs[dx];
+            const bool rel = (dx * dx < rem) && !(dx == 0 && dy == 0) && (st == 1 || st == 2);
+            rejected |= rel && (st == 2) && (sq > s);  // (R)
+            blocked |= rel && (sq >= s);
+          }
         }
       }
-    } else {
-      for (int dy = -r; dy <= r && !rejected; ++dy) {
-        const int rem = md2 - dy * dy;  // dx*dx < rem
-        const double* rs = ts + (cy + dy) * lw + cx;
-        const uint8_t* rq = tq + (cy + dy) * lw + cx;
-        for (int dx = -r; dx <= r; ++dx) {
-          const uint8_t st = rq[dx];
-          const double sq = rs[dx];
-          const bool rel = (dx * dx < rem) && !(dx == 0 && dy == 0) && (st == 1 || st == 2);
-          rejected |= rel && (st == 2) && (sq > s);  // (R)
-          blocked |= rel && (sq >= s);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (listed) {  // the 3x3 maxima: the whole disc, sixteen lanes per pixel
-    const int nsur = n_sur, side = 2 * r + 1, ntap = side * side;
-    const int g = tid >> 4, l16 = tid & 15, gsh = (g & 3) * 16;
-    for (int base = 0; base < nsur; base += 16) {
-      const int e = base + g;
-      const bool live = e < nsur;
-      const int t = live ? sur_idx[e] : 0;
-      const int ccx = (t & 63) + r, ccy = (t >> 6) + r;
-      const double ss = ts[ccy * lw + ccx];
-      bool hit = false;
-      if (live)
-        for (int k = l16; k < ntap; k += 16) {
-          const int dy = k / side - r, dx = k - (k / side) * side - r;
-          const uint8_t st = tq[(ccy + dy) * lw + ccx + dx];
-          const double sq = ts[(ccy + dy) * lw + ccx + dx];
-          hit |= (dx * dx + dy * dy < md2) && !(dx == 0 && dy == 0) && (st == 1 || st == 2) && (sq >= ss);
-        }
-      const unsigned any = (unsigned)((__ballot(hit) >> gsh) & 0xffffull);
-      if (live && l16 == 0 && any) sur_blocked[t] = 1;
     }
     __syncthreads();
-    if (mine == 1 && !rejected && !blocked) blocked = sur_blocked[tid] != 0;
+    if (listed) {  // the 3x3 maxima: the whole disc, sixteen lanes per pixel
+      const int nsur = n_sur, side = 2 * r + 1, ntap = side * side;
+      const int g = tid >> 4, l16 = tid & 15, gsh = (g & 3) * 16;
+      for (int base = 0; base < nsur; base += 16) {
+        const int e = base + g;
+        const bool live = e < nsur;
+        const int t = live ? sur_idx[e] : 0;
+        const int ccx = (t & 63) + r, ccy = (t >> 6) + r;
+        const double ss = ts[ccy * lw + ccx];
+        bool hit = false;
+        if (live)
+          for (int k = l16; k < ntap; k += 16) {
+            const int dy = k / side - r, dx = k - (k / side) * side - r;
+            const uint8_t st = tq[(ccy + dy) * lw + ccx + dx];
+            const double sq = ts[(ccy + dy) * lw + ccx + dx];
+            hit |= (dx * dx + dy * dy < md2) && !(dx == 0 && dy == 0) && (st == 1 || st == 2) && (sq >= ss);
+          }
+        const unsigned any = (unsigned)((__ballot(hit) >> gsh) & 0xffffull);
+        if (live && l16 == 0 && any) sur_blocked[t] = 1;
+      }
+      __syncthreads();
+      if (st_mine == 1 && !rejected && !blocked) blocked = sur_blocked[tid] != 0;
+    }
+    // every scan of this sweep has read the tile: decisions become visible
+    const bool decided = st_mine == 1 && (rejected || !blocked);
+    const int any_decided = __syncthreads_or(decided);
+    if (decided) {
+      st_mine = rejected ? 3 : 2;
+      tq[cy * lw + cx] = st_mine;
+      wrote = true;
+      if (st_mine == 2) {
+        const int k = atomicAdd(&n_acc, 1);
+        if (k < SR_MAXACC) acc_idx[k] = (unsigned short)(cy * lw + cx);
+      }
+    }
+    if (!any_decided) break;
+    __syncthreads();
   }
-  if (mine == 1 && (rejected || !blocked)) {
-    state[(size_t)y * w + x] = rejected ? 3 : 2;
+  if (wrote) {
+    state[(size_t)y * w + x] = st_mine;
     *changed = 1;
   }
 }
@@ -663,6 +686,9 @@ void sfmx_release_graphs(sfmx_ctx* c) {
     }
 }
 #define SHI_SPEC 4096
+#ifndef SHI_INNER_SWEEPS
+#define SHI_INNER_SWEEPS 1
+#endif
 #ifndef SHI_TILED_SWEEPS
 #define SHI_TILED_SWEEPS 5
 #endif
@@ -694,6 +720,7 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
     dim3 gt((p->w + SR_TX - 1) / SR_TX, (p->h + SR_TY - 1) / SR_TY);
     // SFMX_SHI_SWEEPS="tiled,list,tail" overrides the schedule (A/B; any schedule is exact: undecided pixels travel to the host)
     static int tiled_sweeps = SHI_TILED_SWEEPS, list_sweeps = SHI_LIST_SWEEPS, tail_sweeps = SHI_TAIL_SWEEPS;
+    static const int inner_sweeps = getenv("SFMX_SHI_INNER") ? std::max(1, std::min(8, atoi(getenv("SFMX_SHI_INNER")))) : SHI_INNER_SWEEPS;
     static const bool parsed = [] {
       if (const char* e = getenv("SFMX_SHI_SWEEPS")) {
         int a = -1, b = -1, t = -1;
@@ -705,7 +732,7 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
     }();
     (void)parsed;
     for (int k = 0; k < tiled_sweeps; ++k)  // dense phase: LDS-tiled sweeps over all pixels
-      k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed);
+      k_shi_round<<<gt, 256, shm, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_changed, inner_sweeps);
     const int npx = p->w * p->h;
     uint32_t* list0 = c->wl[0].as<uint32_t>();
     uint32_t* list1 = c->wl[1].as<uint32_t>();
