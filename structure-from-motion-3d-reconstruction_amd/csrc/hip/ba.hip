@@ -711,7 +711,8 @@ __global__ __launch_bounds__(64) void k_solve_regs_stamps(const double* __restri
 // solve_regs_wave and publishes dx | status (to `work`, and to pinned host memory with a sequence word when `host_out`
 // is given): one BA iteration is two launches (points + expansion, reduction + solve) instead of five.
 #define BAR_COLS 16
-#define BAR_NBUF 3                    // LDS tiles in rotation: one being summed, two on their way
+#define BAR_NBUF 3                    // LDS tiles in rotation
+#define BAR_NPF 4                     // tiles whose loads are in flight in registers
 #define BAR_Q (256 / BAR_COLS)        // point phases per tile pass
 // LDS: 2 arrays x 3 tiles x 64 rows x 16 columns x 8 B = 48 KiB per workgroup (a 128 KiB double buffer could not start
 // on a CU that still held KLT workgroups, and the kernel took 2-3 x longer inside the pipeline than alone).
@@ -742,58 +743,81 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
   const bool two = is_b || diag_blk;
   const bool any_two = __any(two);  // uniform over the block: every wave holds the same BAR_COLS columns
   const int ntiles = (P + BAR_TP - 1) / BAR_TP;
-  double rv[BAR_K], ru[BAR_K];
-  auto load_tile = [&](int t) {
+  // Register ring of BAR_NPF tiles: the loads of tile t + BAR_NPF are issued when tile t is parked in LDS, i.e. BAR_NPF
+  // chain durations (~0.6 us each) before they are needed -- more than the ~2 us a load takes under load.  (With a
+  // look-ahead of one tile every iteration waited ~1 us for its loads: 24 us for the 10 tiles of a 600-point window.)
+  double rv[BAR_NPF][BAR_K], ru[BAR_NPF][BAR_K];
+  auto load_tile = [&](int t, double (&pv)[BAR_K], double (&pu)[BAR_K]) {
 #pragma unroll
     for (int k = 0; k < BAR_K; k++) {
       const int p = min(t * BAR_TP + k * BAR_Q + q, P - 1);
       const double* row = C + (size_t)p * CS;
       const double v = row[o2];
-      rv[k] = is_b ? -v : v;
-      ru[k] = two ? row[o1] : 0.0;
+      pv[k] = is_b ? -v : v;
+      pu[k] = two ? row[o1] : 0.0;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const double (&pv)[BAR_K], const double (&pu)[BAR_K]) {
 #pragma unroll
     for (int k = 0; k < BAR_K; k++) {
-      sv[buf][k * BAR_Q + q][col] = rv[k];
-      su[buf][k * BAR_Q + q][col] = ru[k];
+      sv[buf][k * BAR_Q + q][col] = pv[k];
+      su[buf][k * BAR_Q + q][col] = pu[k];
     }
   };
   double acc = 0.0;
-  for (int t = 0; t < 2 && t < ntiles; t++) {  // prologue: tiles 0 and 1
-    load_tile(t);
-    store_tile(t);
-  }
-  __syncthreads();
-  for (int t = 0; t < ntiles; t++) {
-    if (t + 2 < ntiles) load_tile(t + 2);  // in flight while tile t is summed (tile t+1 already sits in LDS)
-    if (tid < BAR_COLS) {
-      const int buf = t % BAR_NBUF, cnt = min(BAR_TP, P - t * BAR_TP);
-      int pp = 0;
-      if (any_two) {
-        for (; pp + 8 <= cnt; pp += 8) {
-          double u[8], v[8];
 #pragma unroll
-          for (int k = 0; k < 8; k++) { u[k] = su[buf][pp + k][col]; v[k] = sv[buf][pp + k][col]; }
+  for (int j = 0; j < BAR_NPF; j++)
+    if (j < ntiles) load_tile(j, rv[j], ru[j]);
+  for (int t0 = 0; t0 < ntiles; t0 += BAR_NPF) {
 #pragma unroll
-          for (int k = 0; k < 8; k++) { acc += u[k]; acc += v[k]; }  // S += Hxx ; S += G_a Hxp_b^T (reference ADDS, Q6) | b += bx ; b -= G*bp
+    for (int j = 0; j < BAR_NPF; j++) {
+      const int t = t0 + j;
+      if (t < ntiles) {  // uniform
+        const int buf = t % BAR_NBUF;  // held tile t-3, whose chain finished before the barrier of tile t-2
+        store_tile(buf, rv[j], ru[j]);
+        if (t + BAR_NPF < ntiles) load_tile(t + BAR_NPF, rv[j], ru[j]);
+        __syncthreads();
+        if (tid < BAR_COLS) {
+          // the LDS reads of the next batch of rows are issued before the dependent adds of the current one
+          const int cnt = min(BAR_TP, P - t * BAR_TP);
+          if (cnt == BAR_TP) {
+            if (any_two) {
+              double u[2][8], v[2][8];
+#pragma unroll
+              for (int k = 0; k < 8; k++) { u[0][k] = su[buf][k][col]; v[0][k] = sv[buf][k][col]; }
+#pragma unroll
+              for (int bch = 0; bch < BAR_TP / 8; bch++) {
+                if (bch + 1 < BAR_TP / 8) {
+#pragma unroll
+                  for (int k = 0; k < 8; k++) { u[(bch + 1) & 1][k] = su[buf][(bch + 1) * 8 + k][col]; v[(bch + 1) & 1][k] = sv[buf][(bch + 1) * 8 + k][col]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) { acc += u[bch & 1][k]; acc += v[bch & 1][k]; }  // S += Hxx ; S += G_a Hxp_b^T (reference ADDS, Q6) | b += bx ; b -= G*bp
+              }
+            } else {
+              double v[2][16];
+#pragma unroll
+              for (int k = 0; k < 16; k++) v[0][k] = sv[buf][k][col];
+#pragma unroll
+              for (int bch = 0; bch < BAR_TP / 16; bch++) {
+                if (bch + 1 < BAR_TP / 16) {
+#pragma unroll
+                  for (int k = 0; k < 16; k++) v[(bch + 1) & 1][k] = sv[buf][(bch + 1) * 16 + k][col];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc += v[bch & 1][k];
+              }
+            }
+          } else if (any_two) {  // the last, partial tile
+            for (int pp = 0; pp < cnt; pp++) { acc += su[buf][pp][col]; acc += sv[buf][pp][col]; }
+          } else {
+            for (int pp = 0; pp < cnt; pp++) acc += sv[buf][pp][col];
+          }
         }
-        for (; pp < cnt; pp++) { acc += su[buf][pp][col]; acc += sv[buf][pp][col]; }
-      } else {
-        for (; pp + 16 <= cnt; pp += 16) {
-          double v[16];
-#pragma unroll
-          for (int k = 0; k < 16; k++) v[k] = sv[buf][pp + k][col];
-#pragma unroll
-          for (int k = 0; k < 16; k++) acc += v[k];
-        }
-        for (; pp < cnt; pp++) acc += sv[buf][pp][col];
       }
     }
-    if (t + 2 < ntiles) store_tile((t + 2) % BAR_NBUF);  // that buffer held tile t-1, summed before the previous barrier
-    __syncthreads();
   }
+  __syncthreads();  // the LDS tiles are reused by the solve below
   if (tid < BAR_COLS && valid) {
     if (is_b) {
       if (damp && i < 6) acc = 0.0;  // T:1070
