@@ -163,6 +163,30 @@ def test_c5_image_size_1920x1080_vs_oracle(ctx):
     To.close()
 
 
+@pytest.mark.parametrize("min_distance", [1, 2, 3, 5, 8, 13, 16])
+def test_corner_pick_for_every_min_distance_vs_oracle(ctx, min_distance):
+    """shi_tomasi's greedy pick (T:286-300) through the tracker seam for the disc radii the device fixpoint supports:
+    min_distance 1 takes the plain-scan path of k_shi_round (no neighbours at all), 2..16 the accepted-list / direct-neighbour
+    path with discs of 1..15 pixels.  Reset (frame 0) and one replenish (frame 1), tracks bit-equal to the oracle's."""
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    seq = synth.make_sequence(2, 320, 240, 0.4, n_blobs=5000, seed=40 + min_distance)
+    kw = dict(max_tracks=4000, min_tracks=3900, quality=0.01, min_distance=min_distance, levels=3, radius=5, iters=10, fb=1.0)
+    Tg = pipe.Tracker(ctx, 320, 240, **kw)
+    To = H.Tracker(O, "orc", **kw)
+    for f in range(2):
+        gp, gc, gi = Tg.step(seq["images"][f])
+        op, oc, oi = To.step(seq["images"][f])
+        assert np.array_equal(gi, oi), (min_distance, f)
+        H.assert_bits_equal(gc, oc, f"cur {f}")
+        gxy, gid = Tg.tracks()
+        oxy, oid = To.tracks()
+        assert np.array_equal(gid, oid), (min_distance, f)
+        H.assert_bits_equal(gxy, oxy, f"tracks min_distance={min_distance} frame {f}")
+    assert len(gid) > 0
+    Tg.close()
+    To.close()
+
+
 def test_klt_empty_and_radius_limits(ctx, golden):
     pa, pb = ctx.pyramid(golden["klt_a"], 3), ctx.pyramid(golden["klt_b"], 3)
     fwd, back, keep, steps = ctx.klt_track(pa, pb, np.zeros((0, 2)))
