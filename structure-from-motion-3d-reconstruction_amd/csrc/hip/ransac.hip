@@ -521,12 +521,14 @@ int sfmx_ransac_score_ex(sfmx_ctx* c, const double* xi, const double* xj, int n,
     *d_rows = reinterpret_cast<const double*>(c->d[1].as<char>() + ioff);
     return SFMX_OK;
   };
-  if (!exact_it.empty()) {  // overlaps with k_hypotheses (the host part) and is ordered behind it (the copy + scatter)
-    const double* d_rows = nullptr;
-    const int rc = upload_exact(exact_it, &d_rows);
-    if (rc != SFMX_OK) return rc;
+  if (!exact_it.empty()) {  // overlaps with k_hypotheses (the host part) and is ordered behind it (the scatter)
+    // the scatter kernel reads the ~10 KB of iteration numbers and exact rows straight out of the pinned staging area
     const int m = (int)exact_it.size();
-    k_patch_E<<<(m * 9 + 255) / 256, 256, 0, c->stream>>>(d_E, d_cond, c->d[1].as<int32_t>(), d_rows, m);
+    const size_t ioff = pad8((size_t)m * 4);
+    memcpy(hpatch, exact_it.data(), (size_t)m * 4);
+    sfmx_exact_eight_point_batch(xi, xj, idx8, exact_it.data(), m, reinterpret_cast<double*>(hpatch + ioff));
+    k_patch_E<<<(m * 9 + 255) / 256, 256, 0, c->stream>>>(d_E, d_cond, reinterpret_cast<const int32_t*>(hpatch),
+                                                         reinterpret_cast<const double*>(hpatch + ioff), m);
   }
   // counts and a copy of the conditioning estimates go straight into the pinned result slab (zero-copy writes)
   int32_t* h_cnt = c->h[1].as<int32_t>();
