@@ -369,6 +369,28 @@ def main():
                              "algorithmic FP64 flop/s over the vector FP64 peak, `hbm` the same launch against the HBM roof",
                         kernel_us_per_pass={k: round(v[0], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])},
                         kernel_launches_per_pass={k: v[1] for k, v in kern.items()})
+        # the same kernel with the device to itself (the pipeline runs 2-3 kernels side by side, which stretches each of them):
+        # KLT of the first frame pair at this run's launch size, HIP events inside the library
+        if dom == "k_klt_track":
+            try:
+                trk = pipe.Tracker(ctx, w, h, max_tracks=args.max_tracks)
+                trk.step(seq["images"][0])
+                pts, _ = trk.tracks()
+                trk.close()
+                pts = np.ascontiguousarray(pts[:max(1, int(round(tracks)))])
+                pa, pb = ctx.pyramid(seq["images"][0], 3), ctx.pyramid(seq["images"][1], 3)
+                ctx.set_timing(True)
+                us, steps_alone = [], 0
+                for _ in range(7):
+                    _, _, _, steps_alone = ctx.klt_track(pa, pb, pts)
+                    us.append(ctx.last_kernel_us())
+                ctx.set_timing(False)
+                us_med = float(np.median(us))
+                tf = LK_STEP_FLOP * steps_alone / (us_med * 1e-6) / 1e12
+                roofline["alone"] = dict(tracks=int(len(pts)), lk_steps=int(steps_alone), avg_launch_us=round(us_med, 2), achieved=round(tf, 4),
+                                         frac=round(tf / FP64_VALU_PEAK_TF, 5))
+            except Exception as e:  # the line must still be printed
+                roofline["alone"] = {"error": repr(e)}
         out = {
             "metric": "keyframes/sec (KLT + RANSAC + local BA per-frame loop), synthetic TempleRing-47 stand-in",
             "value": round(kf_total / dt, 3), "unit": "keyframes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
