@@ -64,21 +64,18 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   return r;
 }
 __device__ __forceinline__ Rot half_angle_fast(double y, double x) {
+  // branch-free: the four hypotheses of a wave take different sign cases, and a divergent branch runs both rsqrt chains
   Rot r;
   const double d = y * y + x * x;
-  if (!(d > 0.0) || !(d < 1e300)) return half_angle(y, x);
   const double rh = rsqrt_nr(d);
   const double c2 = x * rh, s2 = y * rh;
-  if (x >= 0.0) {
-    const double u = 0.5 * (1.0 + c2), ru = rsqrt_nr(u);
-    r.c = u * ru;
-    r.s = 0.5 * s2 * ru;
-  } else {
-    const double u = 0.5 * (1.0 - c2), ru = rsqrt_nr(u);
-    const double sa = u * ru;
-    r.s = (y < 0.0) ? -sa : sa;
-    r.c = 0.5 * fabs(s2) * ru;
-  }
+  const bool pos = x >= 0.0;
+  const double u = 0.5 * (1.0 + (pos ? c2 : -c2)), ru = rsqrt_nr(u);
+  const double m = u * ru;                                    // sqrt(u)
+  const double hs = 0.5 * (pos ? s2 : fabs(s2)) * ru;
+  r.c = pos ? m : hs;
+  r.s = pos ? hs : ((y < 0.0) ? -m : m);
+  if (!(d > 0.0) || !(d < 1e300)) return half_angle(y, x);  // rare: zero / huge / NaN pivots
   return r;
 }
 
@@ -203,7 +200,17 @@ __device__ __forceinline__ void pivot_combine(double& v, int& code) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
   const int oc = __builtin_amdgcn_update_dpp(0, code, CTRL, 0xF, 0xF, false);
   const double ov = __hiloint2double(hi, lo);
-  if (ov > v || (ov == v && oc < code)) { v = ov; code = oc; }
+  const bool take = (ov > v) | ((ov == v) & (oc < code));
+  v = take ? ov : v;
+  code = take ? oc : code;
+}
+
+template <int CTRL>
+__device__ __forceinline__ void pivot_combine_key(unsigned long long& k) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)k, CTRL, 0xF, 0xF, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(k >> 32), CTRL, 0xF, 0xF, false);
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  k = o > k ? o : k;
 }
 
 struct HypLds {
@@ -269,29 +276,37 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
   const bool third = t < 4;
   bool active = live;
   bool near_tie = false;  // uniform within the 16-lane group
+  const unsigned long long gmask = 0xffffull << (HG * g);  // this hypothesis' lanes in a wave-wide ballot
   for (int it = 0; it < sweeps; ++it) {
-    double bv = 0.0;
-    int code = 1;  // (0,1): the reference's initial p,q
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-    if (active) {
-      v0 = fabs(L.A[own_off[0]]); v1 = fabs(L.A[own_off[1]]); v2 = third ? fabs(L.A[own_off[2]]) : 0.0;
-      if (v0 > bv) { bv = v0; code = own_code[0]; }
-      if (v1 > bv) { bv = v1; code = own_code[1]; }
-      if (v2 > bv) { bv = v2; code = own_code[2]; }
+    // ---- pivot: arg-max of |a_ij| over the upper triangle, first in row-major order among equals.  The 16 lanes reduce
+    // ONE 64-bit key per entry -- the magnitude's bit pattern with its low byte replaced by 255 - code -- with integer
+    // compares (a (value, code) pair costs two FP64 compares per step).  Magnitudes that differ only in the byte that
+    // was given up are nearly tied by any standard: such a hypothesis is flagged below and re-derived on the host.
+    const double v0 = fabs(L.A[own_off[0]]), v1 = fabs(L.A[own_off[1]]), v2 = third ? fabs(L.A[own_off[2]]) : 0.0;
+    unsigned long long kb;
+    {
+      const unsigned long long k0 = (((v0 == v0) ? (unsigned long long)__double_as_longlong(v0) : 0ull) & ~0xffull) | (unsigned)(255 - own_code[0]);
+      const unsigned long long k1 = (((v1 == v1) ? (unsigned long long)__double_as_longlong(v1) : 0ull) & ~0xffull) | (unsigned)(255 - own_code[1]);
+      const unsigned long long k2 = (((v2 == v2) ? (unsigned long long)__double_as_longlong(v2) : 0ull) & ~0xffull) | (unsigned)(255 - own_code[2]);
+      kb = k0 > k1 ? k0 : k1;
+      kb = kb > k2 ? kb : k2;
     }
-    pivot_combine<0xB1>(bv, code);   // quad_perm [1,0,3,2]
-    pivot_combine<0x4E>(bv, code);   // quad_perm [2,3,0,1]
-    pivot_combine<0x141>(bv, code);  // row_half_mirror
-    pivot_combine<0x140>(bv, code);  // row_mirror
+    pivot_combine_key<0xB1>(kb);   // quad_perm [1,0,3,2]
+    pivot_combine_key<0x4E>(kb);   // quad_perm [2,3,0,1]
+    pivot_combine_key<0x141>(kb);  // row_half_mirror
+    pivot_combine_key<0x140>(kb);  // row_mirror
+    const int code = 255 - (int)(kb & 0xffull);
+    const double bv = __longlong_as_double((long long)(kb & ~0xffull));  // the maximum, up to its last byte
     const int p = code >> 4, q = code & 15;
-    if (active && bv < 1e-12) active = false;  // maxv < 1e-12 -> break
+    // maxv < 1e-12 -> break (linalg.hpp:150), decided on the exact magnitudes: no entry of this hypothesis reaches 1e-12
+    const bool big = (v0 >= 1e-12) | (v1 >= 1e-12) | (v2 >= 1e-12);
+    active = active & ((__ballot(big) & gmask) != 0);
     if (!__any(active)) break;
     {  // a second entry within PIVOT_TIE_BAND of the chosen pivot?
       const double band = bv * (1.0 - PIVOT_TIE_BAND);
-      const bool mine = active && ((v0 >= band && own_code[0] != code) || (v1 >= band && own_code[1] != code) ||
-                                   (third && v2 >= band && own_code[2] != code));
-      const unsigned long long bal = __ballot(mine);
-      near_tie |= ((bal >> (HG * g)) & 0xffffull) != 0;
+      const bool mine = active & (((v0 >= band) & (own_code[0] != code)) | ((v1 >= band) & (own_code[1] != code)) |
+                                  (third & (v2 >= band) & (own_code[2] != code)));
+      near_tie |= (__ballot(mine) & gmask) != 0;
     }
     if (active) {
       // all LDS reads of this rotation are issued together, ahead of the rotation-angle arithmetic
@@ -301,21 +316,21 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
       const double akp = L.A[tr * 9 + p], akq = L.A[tr * 9 + q];
       const Rot r = half_angle_fast(2.0 * apq, aqq - app);
       const double c = r.c, s = r.s;
+      // every lane forms the off-diagonal pair of its row and the closed-form 2x2 pivot block
+      // (J = [[c, s], [-s, c]] on (p,q): a_pp' = c^2 app - 2cs apq + s^2 aqq, a_qq' = s^2 app + 2cs apq + c^2 aqq);
+      // which of them a lane stores is a select, not a branch (the four hypotheses of a wave have different p, q)
+      const double nvp = c * vp - s * vq, nvq = s * vp + c * vq;
+      const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
+      const double cc = c * c, ss = s * s, cs2 = 2.0 * c * s * apq;
+      const double dpp = cc * app - cs2 + ss * aqq, dqq = ss * app + cs2 + cc * aqq;
       if (t < 9) {
-        L.V[t * 9 + p] = c * vp - s * vq;
-        L.V[t * 9 + q] = s * vp + c * vq;
-        if (t != p && t != q) {
-          const double np_ = c * akp - s * akq, nq_ = s * akp + c * akq;
-          L.A[t * 9 + p] = np_; L.A[p * 9 + t] = np_;
-          L.A[t * 9 + q] = nq_; L.A[q * 9 + t] = nq_;
-        } else if (t == p) {
-          // J = [[c, s], [-s, c]] on (p,q): a_pp' = c^2 app - 2cs apq + s^2 aqq, a_qq' = s^2 app + 2cs apq + c^2 aqq
-          const double cc = c * c, ss = s * s, cs2 = 2.0 * c * s * apq;
-          L.A[p * 9 + p] = cc * app - cs2 + ss * aqq;
-          L.A[q * 9 + q] = ss * app + cs2 + cc * aqq;
-          L.A[p * 9 + q] = 0.0;
-          L.A[q * 9 + p] = 0.0;
-        }
+        const bool isp = t == p, isq = t == q;
+        const double w_tp = isp ? dpp : (isq ? 0.0 : np_);  // (t,p) and (p,t); row q: the zeroed pivot entry
+        const double w_tq = isq ? dqq : (isp ? 0.0 : nq_);  // (t,q) and (q,t); row p: the zeroed pivot entry
+        L.V[t * 9 + p] = nvp;
+        L.V[t * 9 + q] = nvq;
+        L.A[t * 9 + p] = w_tp; L.A[p * 9 + t] = w_tp;
+        L.A[t * 9 + q] = w_tq; L.A[q * 9 + t] = w_tq;
       }
     }
     __syncthreads();
