@@ -296,16 +296,17 @@ __device__ __forceinline__ int ba_row_stride(int W) { return 36 * W * W + 36 * W
 //   [.., +D) and [.., +D) bx (T:1018) and G*bp (T:1039-1041)
 // A missing contribution is stored as +0.0: the running sums of k_ba_reduce start at +0.0 and can never become -0.0,
 // so adding +0.0 is the identity and the reduction needs no branches.  (The expansion used to be a launch of its own.)
-// Two shapes: <4, 256> with the expansion (windows of a few hundred points: one launch less on the BA chain), and
-// <64, 64> without it (C == nullptr) followed by k_ba_expand over the whole device (tens of thousands of points, C4).
+// Two shapes (kernels k_ba_points_window / k_ba_points_bulk below): <4, 256> with the expansion (windows of a few hundred
+// points: one launch less on the BA chain), and <64, 64> without it (C == nullptr) followed by k_ba_expand over the whole
+// device (tens of thousands of points, C4).
 #define BA_PTS 4
 #define BA_MERGED_EXPAND_MAX_P 4096
 template <int PTS, int NT>
-__global__ __launch_bounds__(NT) void k_ba_points(int W, int P, int MS, const double* __restrict__ poses, const double* __restrict__ X,
-                                                  const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
-                                                  const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
-                                                  double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C,
-                                                  int wave_prio) {
+__device__ __forceinline__ void ba_points_body(int W, int P, int MS, const double* __restrict__ poses, const double* __restrict__ X,
+                                               const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
+                                               const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
+                                               double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C,
+                                               int wave_prio) {
   // the BA iterations are the longest dependent chain of a keyframe: their waves go first where they share a SIMD with
   // the bulk kernels of the other lanes (KLT, hypotheses, corner sweeps)
   if (wave_prio) __builtin_amdgcn_s_setprio(3);
@@ -360,6 +361,22 @@ __global__ __launch_bounds__(NT) void k_ba_points(int W, int P, int MS, const do
     }
   }
 }
+
+#define BA_POINTS_PARAMS                                                                                                             \
+  int W, int P, int MS, const double *__restrict__ poses, const double *__restrict__ X, const int32_t *__restrict__ obs_ptr,              \
+      const int32_t *__restrict__ obs_li, const double *__restrict__ obs_uv, double fx, double fy, double cx, double cy, double huber,   \
+      double *__restrict__ rec, int8_t *__restrict__ slot_of, double *__restrict__ C, int wave_prio
+#define BA_POINTS_PASS W, P, MS, poses, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of, C, wave_prio
+// The window-sized shape is held to 96 VGPRs (the compiler takes 200 when left alone, 400 B of spills at 96 cost nothing
+// measurable): its four-wave workgroups need room on all four SIMDs of a CU at once, and next to KLT waves (173 VGPRs
+// each, one or two per SIMD) a 200-VGPR wave often finds none -- every launch slower than 60 us in the kernel trace
+// overlapped a KLT launch.  In the pipeline 37 -> 26 us per launch (9.5 us alone either way).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ba_points_window(BA_POINTS_PARAMS) {
+  ba_points_body<BA_PTS, 256>(BA_POINTS_PASS);
+}
+__global__ __launch_bounds__(64) void k_ba_points_bulk(BA_POINTS_PARAMS) { ba_points_body<64, 64>(BA_POINTS_PASS); }
+#undef BA_POINTS_PARAMS
+#undef BA_POINTS_PASS
 
 // the expansion as a launch of its own (large problems): one thread per (point, row element)
 __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
@@ -1231,10 +1248,10 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   static const char* expand_env = getenv("SFMX_BA_EXPAND");  // "split" / "merged": A/B and tests
   const bool merged = expand_env ? expand_env[0] == 'm' : q->P <= BA_MERGED_EXPAND_MAX_P;
   if (merged) {
-    SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<BA_PTS, 256><<<(q->P + BA_PTS - 1) / BA_PTS, 256, 0, c->stream>>>(
+    SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window<<<(q->P + BA_PTS - 1) / BA_PTS, 256, 0, c->stream>>>(
                                     q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
   } else {
-    SFMX_PROF(c, KID_BA_POINTS, (k_ba_points<64, 64><<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx,
+    SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_bulk<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx,
                                                                                          fy, cx, cy, huber, q->rec, q->slot_of, nullptr, wave_prio)));
     const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
     SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
