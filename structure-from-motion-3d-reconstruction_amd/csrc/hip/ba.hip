@@ -728,12 +728,13 @@ __global__ __launch_bounds__(64) void k_solve_regs_stamps(const double* __restri
 // solve_regs_wave and publishes dx | status (to `work`, and to pinned host memory with a sequence word when `host_out`
 // is given): one BA iteration is two launches (points + expansion, reduction + solve) instead of five.
 #define BAR_COLS 16
-#define BAR_NBUF 3                    // LDS tiles in rotation
-#define BAR_NPF 4                     // tiles whose loads are in flight in registers
 #define BAR_Q (256 / BAR_COLS)        // point phases per tile pass
 // LDS: 2 arrays x 3 tiles x 64 rows x 16 columns x 8 B = 48 KiB per workgroup (a 128 KiB double buffer could not start
 // on a CU that still held KLT workgroups, and the kernel took 2-3 x longer inside the pipeline than alone).
-template <int BAR_TP, int SOLVE_N>
+// BAR_NPF: tiles whose loads are in flight in registers; BAR_NBUF: LDS tiles in rotation (2 suffice: tile t+2 is stored after
+// the barrier that follows the chain over tile t).  Window-sized problems run <64, N, 2, 2>: 32 KiB of LDS and ~30 VGPRs
+// less than the streaming shape <64, N, 4, 3> that C4 uses -- a smaller footprint finds a CU sooner next to KLT workgroups.
+template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
 __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
                                                    double* __restrict__ S, double* __restrict__ b,
                                                    unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
     for (int j = 0; j < BAR_NPF; j++) {
       const int t = t0 + j;
       if (t < ntiles) {  // uniform
-        const int buf = t % BAR_NBUF;  // held tile t-3, whose chain finished before the barrier of tile t-2
+        const int buf = t % BAR_NBUF;  // held tile t - BAR_NBUF, whose chain finished before the barrier of the tile after it
         store_tile(buf, rv[j], ru[j]);
         if (t + BAR_NPF < ntiles) load_tile(t + BAR_NPF, rv[j], ru[j]);
         __syncthreads();
@@ -1258,14 +1259,19 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   }
   const int nwg = (D * D + D + BAR_COLS - 1) / BAR_COLS;
   if (fused_solve && q->W == 6) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
                                                                               q->ticket, q->work, host_out, seq, wave_prio)));
   } else if (fused_solve && q->W == 10) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 60><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 60, 4, 3><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
                                                                               q->ticket, q->work, host_out, seq, wave_prio)));
   } else {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                             nullptr, nullptr, nullptr, 0, wave_prio)));
+    if (q->P <= BA_MERGED_EXPAND_MAX_P) {
+      SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+                                                                                     nullptr, nullptr, nullptr, 0, wave_prio)));
+    } else {
+      SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0, 4, 3><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+                                                                                     nullptr, nullptr, nullptr, 0, wave_prio)));
+    }
   }
   t.stop();
   SFMX_HIP(c, hipGetLastError());
