@@ -798,7 +798,27 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
         if (tid < BAR_COLS) {
           // the LDS reads of the next batch of rows are issued before the dependent adds of the current one
           const int cnt = min(BAR_TP, P - t * BAR_TP);
-          if (cnt == BAR_TP) {
+          if (cnt == BAR_TP && BAR_NPF <= 2) {  // window shape: one batch in registers (32 VGPRs less than the look-ahead below)
+            if (any_two) {
+#pragma unroll
+              for (int bch = 0; bch < BAR_TP / 8; bch++) {
+                double u[8], v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { u[k] = su[buf][bch * 8 + k][col]; v[k] = sv[buf][bch * 8 + k][col]; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) { acc += u[k]; acc += v[k]; }
+              }
+            } else {
+#pragma unroll
+              for (int bch = 0; bch < BAR_TP / 16; bch++) {
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = sv[buf][bch * 16 + k][col];
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc += v[k];
+              }
+            }
+          } else if (cnt == BAR_TP) {  // streaming shape: the LDS reads of the next batch ahead of the adds of the current one
             if (any_two) {
               double u[2][8], v[2][8];
 #pragma unroll
