@@ -27,7 +27,7 @@ import sys
 import tempfile
 import time
 
-# One pipeline keeps five contexts busy.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
+# One pipeline keeps eight contexts busy.  HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default
 # 4) in creation order; with 8 the BA lane, the tracker lane and the prefetch lane each get a queue of their own
 # (measured: +15-20 % keyframes/s).  Must be in the environment before the HIP runtime initialises, i.e. before torch.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -305,7 +305,7 @@ def main():
         st = last["stats"]
         # --- roofline of the DOMINANT kernel of this run: the kernel with the largest accumulated GPU time in the
         # per-kernel profile of the extra timed pass (HIP events recorded inside libsfmx on each context's own stream
-        # around every launch, summed over the five contexts of the pipeline).  Nothing here is read from a previous
+        # around every launch, summed over the contexts of the pipeline).  Nothing here is read from a previous
         # round's files; `traffic` comes from the newest committed PMC summary only if it was taken at this launch size.
         kern = {k: v for k, v in prof["kernels"].items() if v[1] > 0}
         w, h = 640, 480
