@@ -28,24 +28,27 @@ class WorkerTeam {
     {
       std::lock_guard<std::mutex> lk(m_);
       stop_ = true;
-      ++epoch_;
     }
     cv_.notify_all();
     for (auto& t : workers_) t.join();
   }
   bool solo() const { return workers_.empty(); }
-  // calls fn(i) for i in [0,n); the calling thread participates.
+  // calls fn(i) for i in [0,n); the calling thread participates.  Only as many workers are woken as there are chunks
+  // beyond the caller's own: most regions are a few dozen 2-5 us solves, and a wake-up costs more than a chunk.
   void parallel_for(int n, const std::function<void(int)>& fn, int grain) {
+    const int chunks = (n + grain - 1) / grain;
+    const int need = std::min((int)workers_.size(), std::max(0, chunks - 1));
     {
       std::lock_guard<std::mutex> lk(m_);
       fn_ = &fn;
       n_ = n;
       grain_ = grain;
       next_.store(0);
-      pending_ = (int)workers_.size();
-      ++epoch_;
+      tickets_ = need;
+      pending_ = need;
     }
-    cv_.notify_all();
+    if (need == (int)workers_.size()) cv_.notify_all();
+    else for (int i = 0; i < need; i++) cv_.notify_one();
     run_chunks();
     std::unique_lock<std::mutex> lk(m_);
     done_cv_.wait(lk, [&] { return pending_ == 0; });
@@ -62,13 +65,12 @@ class WorkerTeam {
     }
   }
   void worker() {
-    unsigned long seen = 0;
     for (;;) {
       {
         std::unique_lock<std::mutex> lk(m_);
-        cv_.wait(lk, [&] { return epoch_ != seen; });
-        seen = epoch_;
+        cv_.wait(lk, [&] { return stop_ || tickets_ > 0; });  // a ticket = the right to join the current region
         if (stop_) return;
+        --tickets_;
       }
       run_chunks();
       {
@@ -81,9 +83,8 @@ class WorkerTeam {
   std::mutex m_;
   std::condition_variable cv_, done_cv_;
   const std::function<void(int)>* fn_ = nullptr;
-  int n_ = 0, grain_ = 16, pending_ = 0;
+  int n_ = 0, grain_ = 16, pending_ = 0, tickets_ = 0;
   std::atomic<int> next_{0};
-  unsigned long epoch_ = 0;
   bool stop_ = false;
 };
 
