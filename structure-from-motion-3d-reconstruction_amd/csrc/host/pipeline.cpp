@@ -441,6 +441,15 @@ bool CornerPrefetcher::take(int frame, std::vector<V2>& corners) {
   slots_.erase(frame);
   return ok;
 }
+bool CornerPrefetcher::take_if_done(int frame, std::vector<V2>& corners) {
+  std::lock_guard<std::mutex> lk(mu_);
+  auto it = slots_.find(frame);
+  if (it == slots_.end() || !it->second.done) return false;
+  const bool ok = !it->second.failed;
+  if (ok) corners = std::move(it->second.corners);
+  slots_.erase(it);
+  return ok;
+}
 void CornerPrefetcher::publish(int frame, std::vector<V2>&& seq, bool failed) {
   {
     std::lock_guard<std::mutex> lk(mu_);
@@ -1175,6 +1184,11 @@ FramePacket FrameFeeder::produce(int fi) {
   p.tracks = tracker_->tracks();
   p.pyr = tracker_->current();
   p.corners = tracker_->take_memo(fi);
+  if (!p.corners && prefetch_) {  // no replenish on this frame: the sequence computed ahead anyway still serves the loop
+    std::vector<V2> seq;          // closure's corner request on this image (T:1841), if it has arrived by now
+    if (prefetch_->take_if_done(fi, seq))
+      p.corners = std::make_shared<const CornerMemo>(CornerMemo{prefetch_->quality(), prefetch_->min_dist(), 0x7fffffff, true, std::move(seq)});
+  }
   clk_->m_step += since(t0);
   const auto td = Clock::now();
   if (on_packet_) on_packet_(p);  // starts the frame->frame RANSAC on lane A before the descriptor download below

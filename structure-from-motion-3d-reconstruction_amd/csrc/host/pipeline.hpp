@@ -160,6 +160,9 @@ class CornerPrefetcher {
   CornerPrefetcher& operator=(const CornerPrefetcher&) = delete;
   void request(int frame);                          // non-blocking; ignored if already requested
   bool take(int frame, std::vector<V2>& corners);   // waits for a requested frame; false if never requested / failed
+  bool take_if_done(int frame, std::vector<V2>& corners);  // the same without waiting: false if not (yet) there
+  double quality() const { return quality_; }
+  int min_dist() const { return min_dist_; }
   void discard_older_than(int frame);               // drop finished results of frames < frame that nobody took
   bool matches(double quality, int min_dist) const { return quality == quality_ && min_dist == min_dist_; }
   double kernel_us();                               // accumulated device time of the workers' score kernels

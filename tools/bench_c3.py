@@ -37,4 +37,4 @@ print(json.dumps({"workload": f"C3 prefix: {a.frames} frames 640x480, max_tracks
                   "klt_fp64_tflops": round(12.7e3 * p["lk_steps"] / max(1, p["klt_calls"]) / (klt_us * 1e-6) / 1e12, 3),
                   "ransac_points_per_call": round(s["ransac_points"] / max(1, s["ransac_calls"]), 1), "map_points": s["n_points"],
                   "n_keyframes": s["n_keyframes"], "frame_generation_s": round(gen_s, 1),
-                  "host_seconds": {k: round(s[k], 4) for k in ("sec_total", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_klt", "sec_ransac", "sec_ba", "sec_shi", "sec_join_wait", "sec_pf_busy", "sec_lane_b_busy", "sec_lane_c_busy")}}))
+                  "host_seconds": {k: round(s[k], 4) for k in ("sec_total", "sec_m_step", "sec_m_ransac", "sec_m_kf", "sec_klt", "sec_ransac", "sec_ba", "sec_shi", "sec_join_wait", "sec_pf_busy", "sec_lane_b_busy", "sec_lane_c_busy", "sec_lane_a_busy", "sec_lane_e_busy", "sec_bookkeeping", "sec_tri_iter", "sec_tri_solve", "sec_tri_insert", "sec_ba_gather", "sec_desc", "sec_feed_wait", "sec_shi_wait")}}))
