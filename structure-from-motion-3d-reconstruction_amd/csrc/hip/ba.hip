@@ -378,38 +378,45 @@ __global__ __launch_bounds__(64) void k_ba_points_bulk(BA_POINTS_PARAMS) { ba_po
 #undef BA_POINTS_PARAMS
 #undef BA_POINTS_PASS
 
-// the expansion as a launch of its own (large problems): one thread per (point, row element)
+// the expansion as a launch of its own (large problems): one workgroup per point; the point's slot records and slot table
+// are staged in LDS once and every thread forms 1/256 of the row from there (one thread per element, each fetching its own
+// six operands from L2, ran at 1.45 TB/s of stores; the row is 32 KB at W = 10)
 __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
                                                    double* __restrict__ C) {
+  __shared__ double srec[BA_MAX_OBS * BA_SLOT];
+  __shared__ int8_t sso[BA_MAX_W];
   const int D = 6 * W, CS = ba_row_stride(W);
-  const int p = blockIdx.y;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= CS) return;
-  const int8_t* so = slot_of + (size_t)p * W;
+  const int p = blockIdx.x, tid = threadIdx.x;
   const double* base = rec + (size_t)p * MS * BA_SLOT;
-  double v = 0.0;
-  if (e < D * D) {
-    const int i = e / D, j = e % D;
-    const int sa = so[i / 6], sb = so[j / 6];
-    if (sa >= 0 && sb >= 0) {
-      const double* g = base + (size_t)sa * BA_SLOT + 60 + (i % 6) * 3;
-      const double* h = base + (size_t)sb * BA_SLOT + 42 + (j % 6) * 3;
-      v = g[0] * h[0] + g[1] * h[1] + g[2] * h[2];
+  for (int k = tid; k < MS * BA_SLOT; k += 256) srec[k] = base[k];
+  if (tid < W) sso[tid] = slot_of[(size_t)p * W + tid];
+  __syncthreads();
+  double* row = C + (size_t)p * CS;
+  for (int e = tid; e < CS; e += 256) {
+    double v = 0.0;
+    if (e < D * D) {
+      const int i = e / D, j = e - i * D;
+      const int sa = sso[i / 6], sb = sso[j / 6];
+      if (sa >= 0 && sb >= 0) {
+        const double* g = srec + sa * BA_SLOT + 60 + (i % 6) * 3;
+        const double* h = srec + sb * BA_SLOT + 42 + (j % 6) * 3;
+        v = g[0] * h[0] + g[1] * h[1] + g[2] * h[2];
+      }
+    } else if (e < D * D + 36 * W) {
+      const int k = e - D * D;
+      const int sa = sso[k / 36];
+      if (sa >= 0) v = srec[sa * BA_SLOT + (k % 36)];
+    } else if (e < D * D + 36 * W + D) {
+      const int i = e - (D * D + 36 * W);
+      const int sa = sso[i / 6];
+      if (sa >= 0) v = srec[sa * BA_SLOT + 36 + (i % 6)];
+    } else {
+      const int i = e - (D * D + 36 * W + D);
+      const int sa = sso[i / 6];
+      if (sa >= 0) v = srec[sa * BA_SLOT + 78 + (i % 6)];
     }
-  } else if (e < D * D + 36 * W) {
-    const int k = e - D * D;
-    const int sa = so[k / 36];
-    if (sa >= 0) v = base[(size_t)sa * BA_SLOT + (k % 36)];
-  } else if (e < D * D + 36 * W + D) {
-    const int i = e - (D * D + 36 * W);
-    const int sa = so[i / 6];
-    if (sa >= 0) v = base[(size_t)sa * BA_SLOT + 36 + (i % 6)];
-  } else {
-    const int i = e - (D * D + 36 * W + D);
-    const int sa = so[i / 6];
-    if (sa >= 0) v = base[(size_t)sa * BA_SLOT + 78 + (i % 6)];
+    row[e] = v;
   }
-  C[(size_t)p * CS + e] = v;
 }
 
 // ------------------------------------------------------------------------------------------ dense solve
@@ -1274,8 +1281,7 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   } else {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_bulk<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx,
                                                                                          fy, cx, cy, huber, q->rec, q->slot_of, nullptr, wave_prio)));
-    const int CS = 36 * q->W * q->W + 36 * q->W + 12 * q->W;
-    SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<dim3((CS + 255) / 256, q->P), 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
+    SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<q->P, 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
   }
   const int nwg = (D * D + D + BAR_COLS - 1) / BAR_COLS;
   if (fused_solve && q->W == 6) {
