@@ -739,8 +739,9 @@ __global__ __launch_bounds__(64) void k_solve_regs_stamps(const double* __restri
 // LDS: 2 arrays x 3 tiles x 64 rows x 16 columns x 8 B = 48 KiB per workgroup (a 128 KiB double buffer could not start
 // on a CU that still held KLT workgroups, and the kernel took 2-3 x longer inside the pipeline than alone).
 // BAR_NPF: tiles whose loads are in flight in registers; BAR_NBUF: LDS tiles in rotation (2 suffice: tile t+2 is stored after
-// the barrier that follows the chain over tile t).  Window-sized problems run <64, N, 2, 2>: 32 KiB of LDS and ~30 VGPRs
-// less than the streaming shape <64, N, 4, 3> that C4 uses -- a smaller footprint finds a CU sooner next to KLT workgroups.
+// the barrier that follows the chain over tile t).  Window-sized problems run <64, N, 2, 2>: 32 KiB of LDS and 96 VGPRs -- a
+// small footprint finds a CU sooner next to KLT workgroups.  The streaming shape that C4 uses is <128, N, 2, 2>: 64 KiB of
+// LDS, half as many barriers per point (C4 reduction 1.14 -> 0.91 ms; <64, N, 4, 3> before).
 template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
 __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
                                                    double* __restrict__ S, double* __restrict__ b,
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
         if (tid < BAR_COLS) {
           // the LDS reads of the next batch of rows are issued before the dependent adds of the current one
           const int cnt = min(BAR_TP, P - t * BAR_TP);
-          if (cnt == BAR_TP && BAR_NPF <= 2) {  // window shape: one batch in registers (32 VGPRs less than the look-ahead below)
+          if (cnt == BAR_TP && BAR_NPF <= 2 && BAR_TP <= 64) {  // window shape: one batch in registers (32 VGPRs less than the look-ahead below)
             if (any_two) {
 #pragma unroll
               for (int bch = 0; bch < BAR_TP / 8; bch++) {
@@ -1288,14 +1289,14 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
     SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
                                                                               q->ticket, q->work, host_out, seq, wave_prio)));
   } else if (fused_solve && q->W == 10) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 60, 4, 3><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 60, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
                                                                               q->ticket, q->work, host_out, seq, wave_prio)));
   } else {
     if (q->P <= BA_MERGED_EXPAND_MAX_P) {
       SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
                                                                                      nullptr, nullptr, nullptr, 0, wave_prio)));
     } else {
-      SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0, 4, 3><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
+      SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
                                                                                      nullptr, nullptr, nullptr, 0, wave_prio)));
     }
   }
