@@ -4,17 +4,17 @@
 // The reference accumulates S (6W x 6W) and b point after point, so every element of S,b is an
 // ORDERED floating-point sum over the points; parity is bit-exact, so the order is kept:
 //
-//  k_ba_points  (parallel over points, one lane per point): residuals, analytic Jacobians, Huber
-//      weights, per-point Hpp/bp and per-(point,pose) Hxx/bx/Hxp exactly as T:920-1009, then
-//      inv3(Hpp) and G = Hxp * Hpp^-1, G*bp (T:1011-1041).  Output is one compact RECORD per point
-//      (84 doubles per observing pose) plus a pose->slot table; poses (W x 12 doubles) sit in LDS.
-//  k_ba_expand  (parallel over point x element): every addend the reference will add into S,b for
-//      this point -- the Schur term G_a * Hxp_b^T per element, Hxx, bx, G*bp -- written as one
-//      contiguous contribution row per point.
-//  k_ba_reduce  (one lane per element of S and b): ordered column sum over the contribution rows in
-//      the reference's sequence (T:1015-1057): Hxx first, then the Schur term (which the reference
-//      ADDS, quirk Q6), bx then -G*bp for b; finally damping and gauge (T:1064-1071).  Coalesced
-//      loads run 16 points ahead of the dependent add chain, which is the only serial part.
+//  k_ba_points_window / k_ba_points_bulk: residuals, analytic Jacobians, Huber weights, per-point Hpp/bp and
+//      per-(point,pose) Hxx/bx/Hxp exactly as T:920-1009, then inv3(Hpp) and G = Hxp * Hpp^-1, G*bp (T:1011-1041).
+//      Output is one compact RECORD per point (84 doubles per observing pose) plus a pose->slot table; poses (W x 12
+//      doubles) sit in LDS.  Window shape: sixteen lanes per point (one per observation), followed in the same launch by
+//  the expansion (k_ba_expand for large problems): every addend the reference will add into S,b for a point -- the
+//      Schur term G_a * Hxp_b^T per element, Hxx, bx, G*bp -- written as one contiguous contribution row per point.
+//  k_ba_reduce  (16 elements of S | b per workgroup): ordered column sums over the contribution rows in the reference's
+//      sequence (T:1015-1057): Hxx first, then the Schur term (which the reference ADDS, quirk Q6), bx then -G*bp for
+//      b; finally damping and gauge (T:1064-1071).  Tiles of rows stream through a register ring and LDS ahead of the
+//      dependent add chains, which are the only serial part.  For windows of 6 / 10 poses the workgroup that finishes
+//      last also solves the system (solve_regs_wave) and publishes dx to pinned host memory.
 //  k_solve_regs / k_solve_wave (one wavefront) and the blocked k_lu_* kernels (whole device): partial-pivoting
 //      elimination with the reference's first-maximum pivot rule, row normalisation, |f| < 1e-18 skip and ascending
 //      back-substitution.
