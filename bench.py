@@ -78,14 +78,14 @@ def cpu_baseline(seq, cfg, sample_frames: int):
                 frames_per_s=sample_frames / dt)
 
 
-def bench_ba_sharded(args, capi, synth, rank, local_rank, world):
+def run_ba_sharded(capi, synth, rank, local_rank, world, steps, warmup, ctx=None, comm=None):
     """BASELINE config C4: local BA on W=10 poses, P=50 000 points, every point seen by every pose (500 k residuals), points
     sharded over the ranks; a step = one BA iteration = partial build of S|b on this rank's points, RCCL all-reduce(sum) of
-    D*D + D = 3 660 doubles in HBM, damping + gauge, dense solve on the device, dx to the host."""
+    D*D + D = 3 660 doubles in HBM, damping + gauge, dense solve on the device, dx to the host.  torch.distributed must be
+    up when world > 1 (it carries the unique id and the max-time reduction).  Returns the result dict (meaningful on rank 0)."""
     import torch
     import torch.distributed as dist
     D = importlib.import_module(PKG + ".dist")
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
     W, P = 10, 50000
     rng = np.random.default_rng(1)
     pw = np.zeros((W, 12))
@@ -99,10 +99,11 @@ def bench_ba_sharded(args, capi, synth, rank, local_rank, world):
     Xc = np.einsum("kij,pj->pki", pw[:, :9].reshape(W, 3, 3), X) + pw[None, :, 9:]
     uv = np.stack([K[0, 0] * Xc[..., 0] / Xc[..., 2] + K[0, 2], K[1, 1] * Xc[..., 1] / Xc[..., 2] + K[1, 2]], -1)
     uv = np.ascontiguousarray((uv + rng.normal(size=uv.shape) * 0.5).reshape(P * W, 2))
-    ctx = capi.Context(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    comm = D.make_comms(1, local_rank)[0]
+    own_ctx, own_comm = ctx is None, comm is None
+    if own_ctx:
+        ctx = capi.Context(local_rank)
+    if own_comm:
+        comm = D.make_comms(1, local_rank)[0]
     lo, hi = capi.shard_range(P, rank, world)
     o0, o1 = int(ptr[lo]), int(ptr[hi])
     prob = ctx.ba_problem(W, X[lo:hi], ptr[lo:hi + 1] - o0, li[o0:o1], uv[o0:o1])
@@ -113,11 +114,11 @@ def bench_ba_sharded(args, capi, synth, rank, local_rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         rc, dx = prob.step_sharded(comm, *a)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         rc, dx = prob.step_sharded(comm, *a)
     ctx.sync()
     barrier()
@@ -131,33 +132,49 @@ def bench_ba_sharded(args, capi, synth, rank, local_rank, world):
         prob.step_sharded(comm, *a)
     prof = {k: v for k, v in ctx.kernel_profile().items() if v[1] > 0}
     ctx.set_timing(False)
+    Pl, R = hi - lo, (hi - lo) * W
+    # SURVEY.md 8(d) for THIS rank's shard, per BA iteration: 535 flop per residual + (126 n + 180 n^2 + 40) per point (n = W poses
+    # see the point); bytes 20 R + 24 P + 96 W read, 8 (D^2 + D) written -- the figures the roofline is priced on.  What the
+    # kernels move on top of that (the contribution rows) shows up in `kernel_us_per_step`, not in `achieved`.
+    Dd = 6 * W
+    alg_flop = 535.0 * R + Pl * (126.0 * W + 180.0 * W * W + 40.0)
+    alg_bytes = 20.0 * R + 24.0 * Pl + 96.0 * W + 8.0 * (Dd * Dd + Dd)
+    step_s = dt / steps
+    out = {"metric": "BA iterations/sec, BASELINE config C4 (W=10 poses, P=50 000 points, 500 k residuals), points sharded over the ranks",
+           "value": round(steps / dt, 3), "unit": "iterations/s", "n_gpus": world, "rccl_world": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "strong", "mode": "ba-sharded",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "local BA S|b build + reduce + dense solve, W=10, P=50000, every point in every pose, N(0,0.5 px) noise",
+                      "points_per_rank": Pl, "allreduce_doubles": Dd * Dd + Dd, "allreduce_bytes_per_step": 8 * (Dd * Dd + Dd),
+                      "parallelism": f"BA points x{world}, RCCL all-reduce(sum) of S|b in HBM"},
+           "roofline": {"bound": "valu_fp64", "achieved": round(alg_flop / step_s / 1e12, 4), "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(alg_flop / step_s / 1e12 / FP64_VALU_PEAK_TF, 5), "traffic": None,
+                        "algorithmic_flop_per_step": int(alg_flop), "algorithmic_bytes_per_step": int(alg_bytes),
+                        "hbm": {"achieved": round(alg_bytes / step_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 6)},
+                        "note": "whole iteration (all kernels + host round trip) against SURVEY.md 8(d)'s figures for this rank's shard; "
+                                "`traffic` (FETCH_SIZE + WRITE_SIZE per iteration) is in profiles/ when a PMC pass was taken",
+                        "kernel_us_per_step": {k: round(v[0] / v[1], 2) for k, v in prof.items()}},
+           "dx_head": [float(v) for v in dx[6:9]]}
+    prob.close()
+    if own_comm:
+        comm.close()
+    if own_ctx:
+        ctx.close()
+    return out
+
+
+def bench_ba_sharded(args, capi, synth, rank, local_rank, world):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    out = run_ba_sharded(capi, synth, rank, local_rank, world, args.steps, args.warmup)
     if rank == 0:
-        Pl, R = hi - lo, (hi - lo) * W
-        dom = max(prof, key=lambda k: prof[k][0])
-        avg_us = prof[dom][0] / prof[dom][1]
-        # algorithmic figures of SURVEY.md 8(d) for THIS rank's shard: 535 flop per residual + (126 n + 180 n^2 + 40) per point (n = W)
-        flop = {"k_ba_points": 535.0 * R + Pl * (126.0 * W + 180.0 * W * W + 40.0), "k_ba_reduce": 1.0 * Pl * (36 * W * W + 6 * W)}
-        byts = {"k_ba_points": 20.0 * R + 24.0 * Pl + 96.0 * W, "k_ba_reduce": 8.0 * Pl * (36 * W * W + 48 * W),
-                "k_ba_expand": 2 * 8.0 * Pl * (36 * W * W + 48 * W)}
-        ach_gbs = byts[dom] / (avg_us * 1e-6) / 1e9 if dom in byts else None
-        out = {"metric": "BA iterations/sec, BASELINE config C4 (W=10 poses, P=50 000 points, 500 k residuals), points sharded over the ranks",
-               "value": round(args.steps / dt, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "mode": "ba-sharded",
-               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "local BA S|b build + reduce + dense solve, W=10, P=50000, every point in every pose, N(0,0.5 px) noise",
-                          "points_per_rank": Pl, "allreduce_doubles": 60 * 60 + 60, "parallelism": f"BA points x{world}, RCCL all-reduce(sum) of S|b in HBM"},
-               "roofline": {"bound": "hbm", "achieved": None if ach_gbs is None else round(ach_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": None if ach_gbs is None else round(ach_gbs / HBM_PEAK_GBS, 5), "traffic": None, "kernel": dom,
-                            "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(byts.get(dom, 0)),
-                            "kernel_us_per_step": {k: round(v[0] / v[1], 2) for k, v in prof.items()}},
-               "dx_head": [float(v) for v in dx[6:9]]}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    prob.close()
-    comm.close()
-    ctx.close()
 
 
 def main():
@@ -175,6 +192,10 @@ def main():
     ap.add_argument("--batched-probe", type=int, default=3,
                     help="after the headline measurement (1 sequence per GPU) also time this many sequences in flight and "
                          "report it as `batched` (single-GPU runs only; 0 = skip)")
+    ap.add_argument("--sharded-probe", type=int, default=1,
+                    help="default mode: after the headline also time the sharded BA step (C4) and one sequence on all ranks and "
+                         "report them as `sharded_ba` / `sharded_sequence` (0 = skip)")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="watchdog of the sharded sub-benchmarks, seconds")
     ap.add_argument("--mode", choices=("sequences", "ba-sharded", "sharded-sequence"), default="sequences",
                     help="sequences (headline): one independent sequence per rank, weak scaling, no data-path collective; "
                          "ba-sharded: BASELINE config C4 (W=10, P=50 000, 500 k residuals) with the points sharded over the ranks and one "
@@ -204,6 +225,8 @@ def main():
     # (one sequence alone cannot fill the device: its kernels are short dependent chains)
     import threading
     S = max(1, args.sequences_per_gpu)
+    if args.mode == "sharded-sequence":
+        S = 1  # one job on all ranks: a communicator serves ONE pipeline (its collectives must be issued in one order)
     cfg = dict(pipe.DEFAULTS, frames=args.frames, max_tracks=args.max_tracks, min_tracks=min(900, args.max_tracks * 9 // 22),
                export_pointcloud=0)
     seqs, ctxs, devs = [], [], []
@@ -221,7 +244,7 @@ def main():
     seq, ctx, frames_dev = seqs[0], ctxs[0], devs[0]
     shape = tuple(frames_dev.shape)
 
-    comms = None  # sharded-sequence: three native RCCL communicators (BA lane, frame->frame RANSAC lane, keyframe RANSAC lane)
+    comms = None  # sharded-sequence: two native RCCL communicators (BA lane; RANSAC merges of the geometry thread)
 
     def one_pass(timing=False, q=0):
         return pipe.run(ctxs[q], None, seqs[q]["names"], seqs[q]["K"], seqs[q]["lat"], seqs[q]["lon"], cfg, None,
@@ -238,7 +261,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.mode == "sharded-sequence":
-        comms = tuple(importlib.import_module(PKG + ".dist").make_comms(4, local_rank))
+        comms = tuple(importlib.import_module(PKG + ".dist").make_comms(2, local_rank))
 
     def measure(n_seq, n_warm, n_steps):
         """n_seq sequences in flight (one host thread + context each): wall time of n_steps passes of every sequence.
@@ -295,6 +318,81 @@ def main():
 
     # --- one extra, untimed pass with per-kernel HIP-event timing for the roofline object
     prof = one_pass(timing=True)["stats"]
+
+    # --- the north_star's split, measured by the SAME command with the same process group (default mode only): BA points
+    # sharded with an RCCL all-reduce of S | b per iteration (BASELINE config C4), and ONE sequence on all ranks with BA points
+    # and RANSAC hypotheses sharded.  With one rank the same code runs with world-size-1 communicators (no RCCL): the schema
+    # and the code path are exercised by every 1-GPU run.  Both run under a watchdog: a collective that never completes must
+    # not cost the headline line (the sub-object then says so and the process leaves without the RCCL teardown).
+    sharded = {"sharded_ba": None, "sharded_sequence": None}
+    sub_failed = []
+    if args.mode == "sequences" and args.sharded_probe:
+        def sub_benchmarks():
+            Dm = importlib.import_module(PKG + ".dist")
+            # C4 through sfmx_ba_step_sharded
+            try:
+                sharded["sharded_ba"] = run_ba_sharded(capi, synth, rank, local_rank, world, 10, 2)
+            except Exception as e:
+                sharded["sharded_ba"] = {"error": repr(e), "rccl_world": world}
+            # one sequence on all ranks: every rank holds rank 0's sequence
+            try:
+                if rank == 0:
+                    sq, dv = seqs[0], devs[0]
+                else:
+                    sq = synth.make_sequence(args.frames, 640, 480, args.deg_per_frame, n_blobs=20000, seed=7)
+                    dv = torch.from_numpy(np.ascontiguousarray(sq["images"])).to(f"cuda:{local_rank}")
+                    torch.cuda.synchronize()
+                cm = tuple(Dm.make_comms(2, local_rank))
+
+                def sh_pass():
+                    return pipe.run(ctx, None, sq["names"], sq["K"], sq["lat"], sq["lon"], cfg, None, images_dev=dv.data_ptr(),
+                                    shape=tuple(dv.shape), comms=cm)
+                first = sh_pass()
+                barrier()
+                t0 = time.perf_counter()
+                n_sh = max(2, min(args.steps, 5))
+                same = True
+                for _ in range(n_sh):
+                    cur = sh_pass()
+                    same = same and cur["log"] == first["log"] and np.array_equal(cur["centres"].view(np.uint64), first["centres"].view(np.uint64))
+                ctx.sync()
+                barrier()
+                sdt = time.perf_counter() - t0
+                agree = True
+                if world > 1:
+                    tt = torch.tensor([sdt], dtype=torch.float64, device=f"cuda:{local_rank}")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    sdt = float(tt.item())
+                    # every rank must hold the same keyframe centres, bit for bit (the collectives return the same bytes everywhere)
+                    cc = torch.from_numpy(np.ascontiguousarray(first["centres"]).view(np.int64).copy()).to(f"cuda:{local_rank}")
+                    lo_, hi_ = cc.clone(), cc.clone()
+                    dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+                    dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+                    agree = bool(torch.equal(lo_, hi_))
+                stt = first["stats"]
+                ba_it = stt["ba_iters"]
+                sharded["sharded_sequence"] = {
+                    "value": round(stt["n_keyframes"] * n_sh / sdt, 3), "unit": "keyframes/s", "rccl_world": world, "steps": n_sh,
+                    "ms_per_step": round(sdt / n_sh * 1e3, 3), "scaling": "strong", "passes_bit_identical": bool(same),
+                    "ranks_bit_identical": agree, "keyframes_per_step": stt["n_keyframes"],
+                    "collectives_per_step": {"ba_allreduce_sum": int(ba_it), "ba_allreduce_bytes_each": 8 * (36 * 36 + 36),
+                                             "ransac_merges": int(stt["ransac_calls"]), "ransac_merge_bytes_each": 8 + 72},
+                    "same_result_as_unsharded": bool(rank != 0 or (first["log"] == last["log"] and np.allclose(
+                        first["centres"], last["centres"], rtol=1e-6, atol=1e-6 * max(1.0, float(np.abs(last["centres"]).max()))))),
+                    "parallelism": f"one sequence on {world} rank(s): BA points + RANSAC hypotheses sharded; comm_ba on lane B, comm_ransac on the geometry thread"}
+                for m in cm:
+                    m.close()
+            except Exception as e:
+                sharded["sharded_sequence"] = {"error": repr(e), "rccl_world": world}
+
+        th = threading.Thread(target=sub_benchmarks, daemon=True)
+        th.start()
+        th.join(args.sharded_timeout)
+        if th.is_alive():
+            for k in sharded:
+                if sharded[k] is None:
+                    sharded[k] = {"error": f"no result within {args.sharded_timeout} s (watchdog)", "rccl_world": world}
+                    sub_failed.append(k)
     batched = None
     if world == 1 and S == 1 and args.batched_probe > 1:  # how much more the device takes with several sequences in flight
         b_steps = max(2, min(args.steps, 8))
@@ -412,6 +510,7 @@ def main():
         # (structure-from-motion-3d-reconstruction_amd/_build/ate_keyframes; its digits are pinned to the reference tool's
         # in tests/test_tools.py) on the CSV of one extra, untimed pass
         out["batched"] = batched
+        out.update(sharded)
         out["ate_rmse_sim3_vs_gt"] = None
         try:
             import subprocess, tempfile
@@ -435,9 +534,18 @@ def main():
             out["cpu_baseline"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in cb.items()}
             out["speedup_vs_cpu_baseline"] = round(out["value"] / cb["value"], 1) if cb["value"] > 0 else None
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    sys.stdout.flush()
+    if sub_failed:  # a collective is stuck somewhere: no barrier, no RCCL teardown -- the line is out, leave
+        os._exit(0)
+    if world > 1:  # everything is measured and printed: a rank that cannot finish the teardown (a peer left early) just leaves
+        def teardown():
+            dist.barrier()
+            dist.destroy_process_group()
+        th = threading.Thread(target=teardown, daemon=True)
+        th.start()
+        th.join(60.0)
+        if th.is_alive():
+            os._exit(0)
     for c in ctxs:
         c.close()
 

@@ -190,11 +190,21 @@ int sfmx_comm_allreduce_f64(sfmx_ctx* ctx, sfmx_comm* comm, double* host_inout, 
 int sfmx_comm_allreduce_u64_max(sfmx_ctx* ctx, sfmx_comm* comm, uint64_t* host_inout, int n);
 /* Point-sharded BA iteration (T:893-1095): prob holds THIS rank's contiguous range of the window's points (reference
  * order); raw S | b of the shard -> one all-reduce(sum) of D*D + D doubles in HBM -> damping + gauge (T:1064-1071) ->
- * solve on the device -> dx (identical on every rank).  The rank-ordered sum rounds differently from the sequential
- * reference: this mode is held to 1e-9 relative agreement with the single-GPU step, not to bit-exactness; with
- * world == 1 it equals sfmx_ba_step bit for bit. */
+ * solve on the device -> dx (identical on every rank).  TOLERANCE mode: the rank-ordered sum rounds differently from the
+ * sequential reference (1e-9 relative per step; with world == 1 it equals sfmx_ba_step bit for bit), and whole runs of the
+ * reference's BA do NOT stay within the task's 1e-6 of the one-GPU run (tools/virtual_world_probe.py).  The pipeline uses
+ * sfmx_ba_step_sharded_elements below; this entry remains for callers that accept the tolerance (SFMX_BA_SHARD=points). */
 int sfmx_ba_step_sharded(sfmx_ctx* ctx, sfmx_comm* comm, sfmx_ba_problem* prob, const double* poses_wc, double fx,
                          double fy, double cx, double cy, double huber, double lambda, double* dx_out);
+
+/* Element-sharded BA iteration (T:893-1095) -- the sharded mode that keeps the reference's arithmetic.  prob holds the WHOLE
+ * window on every rank.  The per-point records are computed by every rank (replicated); rank r forms and reduces only its
+ * contiguous slice of the elements of S | b (every element's sum runs over all points in the reference's order) and contributes
+ * +0.0 elsewhere, so the all-reduce(sum) of D*D + D doubles only ever adds zeros: S, b and dx are bit-identical to sfmx_ba_step
+ * at any world size.  (sfmx_ba_step_sharded regroups the addends instead; the reference's BA amplifies that rounding
+ * difference -- it ADDS the Schur term, T:1055 -- to a different trajectory within tens of keyframes) */
+int sfmx_ba_step_sharded_elements(sfmx_ctx* ctx, sfmx_comm* comm, sfmx_ba_problem* prob, const double* poses_wc, double fx,
+                                  double fy, double cx, double cy, double huber, double lambda, double* dx_out);
 
 /* ---- dense solve: replaces sfm::solve_gauss (cpp/include/dense.hpp:54-93) -------------------- */
 /* Gaussian elimination with partial pivoting in the reference's operation order; A [n][n]

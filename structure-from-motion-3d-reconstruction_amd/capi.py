@@ -26,7 +26,7 @@ SYMBOLS = [
     "sfmx_last_kernel_us", "sfmx_kernel_profile", "sfmx_kernel_profile_name", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
     "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
     "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_ransac_score_ex", "sfmx_sampson_mask", "sfmx_ba_create",
-    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_ba_step_sharded", "sfmx_solve_dense", "sfmx_posegraph_solve",
+    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_ba_step_sharded", "sfmx_ba_step_sharded_elements", "sfmx_solve_dense", "sfmx_posegraph_solve",
     "sfmx_comm_get_unique_id", "sfmx_comm_create", "sfmx_comm_destroy", "sfmx_comm_rank", "sfmx_comm_world", "sfmx_shard_range",
     "sfmx_comm_allreduce_f64", "sfmx_comm_allreduce_u64_max",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt", "sfmx_debug_klt_slow_steps",
@@ -148,6 +148,17 @@ class BaProblem:
         dx = np.zeros(6 * self.W)
         rc = self.ctx.lib.sfmx_ba_step_sharded(self.ctx.h_, comm.h_ if comm is not None else None, self.h_, _p(poses, c_double), c_double(fx),
                                                c_double(fy), c_double(cx), c_double(cy), c_double(huber), c_double(lam), _p(dx, c_double))
+        if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
+            self.ctx._chk(rc)
+        return rc, dx
+
+    def step_sharded_elements(self, comm, poses_wc, fx, fy, cx, cy, huber, lam):
+        """element-sharded iteration (this problem holds the WHOLE window): bit-identical to step() at any world size"""
+        poses = _f64(poses_wc)
+        dx = np.zeros(6 * self.W)
+        rc = self.ctx.lib.sfmx_ba_step_sharded_elements(self.ctx.h_, comm.h_ if comm is not None else None, self.h_, _p(poses, c_double),
+                                                        c_double(fx), c_double(fy), c_double(cx), c_double(cy), c_double(huber), c_double(lam),
+                                                        _p(dx, c_double))
         if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
             self.ctx._chk(rc)
         return rc, dx

@@ -32,7 +32,8 @@
 
 struct sfmx_ba_problem {
   int W = 0, P = 0, R = 0, MS = 0;
-  DevBuf bufs[11];  // grow-only backing stores, so a problem object can be reset for every BA call
+  DevBuf bufs[12];  // grow-only backing stores, so a problem object can be reset for every BA call ([11]: shard partials of the
+                    // virtual-world test mode, allocated on first use)
   double* X = nullptr;
   int32_t* obs_ptr = nullptr;
   int32_t* obs_li = nullptr;
@@ -381,8 +382,11 @@ __global__ __launch_bounds__(64) void k_ba_points_bulk(BA_POINTS_PARAMS) { ba_po
 // the expansion as a launch of its own (large problems): one workgroup per point; the point's slot records and slot table
 // are staged in LDS once and every thread forms 1/256 of the row from there (one thread per element, each fetching its own
 // six operands from L2, ran at 1.45 TB/s of stores; the row is 32 KB at W = 10)
+// e_lo / e_hi (element-sharded step): only the row entries that feed elements [e_lo, e_hi) of S | b are formed and written --
+// the rank that reduces those elements reads nothing else (entry k < D*D feeds S element k; an Hxx entry feeds the diagonal-block
+// element at the same (row, column); bx and G*bp entries feed b).
 __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
-                                                   double* __restrict__ C) {
+                                                   double* __restrict__ C, int e_lo, int e_hi) {
   __shared__ double srec[BA_MAX_OBS * BA_SLOT];
   __shared__ int8_t sso[BA_MAX_W];
   const int D = 6 * W, CS = ba_row_stride(W);
@@ -392,9 +396,13 @@ __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const d
   if (tid < W) sso[tid] = slot_of[(size_t)p * W + tid];
   __syncthreads();
   double* row = C + (size_t)p * CS;
+  const bool all = e_lo <= 0 && e_hi >= D * D + D;
   for (int e = tid; e < CS; e += 256) {
     double v = 0.0;
+    int feeds;  // the element of S | b this entry is an addend of
     if (e < D * D) {
+      feeds = e;
+      if (!all && (feeds < e_lo || feeds >= e_hi)) continue;
       const int i = e / D, j = e - i * D;
       const int sa = sso[i / 6], sb = sso[j / 6];
       if (sa >= 0 && sb >= 0) {
@@ -404,14 +412,21 @@ __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const d
       }
     } else if (e < D * D + 36 * W) {
       const int k = e - D * D;
-      const int sa = sso[k / 36];
-      if (sa >= 0) v = srec[sa * BA_SLOT + (k % 36)];
+      const int a = k / 36, rc = k % 36;
+      feeds = (6 * a + rc / 6) * D + 6 * a + rc % 6;
+      if (!all && (feeds < e_lo || feeds >= e_hi)) continue;
+      const int sa = sso[a];
+      if (sa >= 0) v = srec[sa * BA_SLOT + rc];
     } else if (e < D * D + 36 * W + D) {
       const int i = e - (D * D + 36 * W);
+      feeds = D * D + i;
+      if (!all && (feeds < e_lo || feeds >= e_hi)) continue;
       const int sa = sso[i / 6];
       if (sa >= 0) v = srec[sa * BA_SLOT + 36 + (i % 6)];
     } else {
       const int i = e - (D * D + 36 * W + D);
+      feeds = D * D + i;
+      if (!all && (feeds < e_lo || feeds >= e_hi)) continue;
       const int sa = sso[i / 6];
       if (sa >= 0) v = srec[sa * BA_SLOT + 78 + (i % 6)];
     }
@@ -746,7 +761,9 @@ template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
 __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
                                                    double* __restrict__ S, double* __restrict__ b,
                                                    unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
-                                                   unsigned long long seq, int wave_prio) {
+                                                   unsigned long long seq, int wave_prio, const double* init = nullptr, int wg_off = 0) {
+  // init (optional, [D*D + D] in S | b layout, may alias S): the chains start from these values instead of +0.0 -- a shard
+  // that continues the running sums of the shard before it (relay mode: the reference's sequence across shards)
   if (wave_prio) __builtin_amdgcn_s_setprio(3);  // see k_ba_points
   constexpr int BAR_K = BAR_TP / BAR_Q;  // rows per thread and tile
   constexpr int TILE_DOUBLES = 2 * BAR_NBUF * BAR_TP * BAR_COLS;
@@ -756,7 +773,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
   double (*su)[BAR_TP][BAR_COLS] = reinterpret_cast<double (*)[BAR_TP][BAR_COLS]>(lds + BAR_NBUF * BAR_TP * BAR_COLS);
   const int D = 6 * W, CS = ba_row_stride(W), NE = D * D + D;
   const int tid = threadIdx.x, col = tid % BAR_COLS, q = tid / BAR_COLS;
-  const int e_raw = blockIdx.x * BAR_COLS + col;
+  const int e_raw = ((int)blockIdx.x + wg_off) * BAR_COLS + col;  // wg_off: element-sharded launches cover a slice of the blocks
   const bool valid = e_raw < NE;
   const int e = valid ? e_raw : NE - 1;
   const bool is_b = e >= D * D;
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
       su[buf][k * BAR_Q + q][col] = pu[k];
     }
   };
-  double acc = 0.0;
+  double acc = (init && tid < BAR_COLS) ? init[e] : 0.0;
 #pragma unroll
   for (int j = 0; j < BAR_NPF; j++)
     if (j < ntiles) load_tile(j, rv[j], ru[j]);
@@ -1262,18 +1279,9 @@ __global__ void k_ba_publish(const double* __restrict__ work, int D, double* __r
 // fused: 0 = sums only; otherwise the last workgroup of the reduction also solves and publishes (D = 36 / 60 only: see
 // ba_can_fuse_solve), to q->work and, if host_out is given, to pinned host memory with sequence word `seq`
 static bool ba_can_fuse_solve(const sfmx_ba_problem* q) { return q->W == 6 || q->W == 10; }
-static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
-                           double huber, double lambda, int damp, KernelTimer& t, bool zero_copy_poses = false, bool fused_solve = false,
-                           double* host_out = nullptr, unsigned long long seq = 0) {
-  SFMX_HIP(c, c->h[0].ensure((size_t)q->W * 96));
-  memcpy(c->h[0].p, poses_wc, (size_t)q->W * 96);
-  // zero_copy_poses: k_ba_points reads the 96 W bytes straight out of the pinned staging buffer (the caller does not touch
-  // it again before it has seen this step's result); otherwise one DMA copy into HBM first
-  const double* d_poses = zero_copy_poses ? c->h[0].as<double>() : q->poses;
-  if (!zero_copy_poses) SFMX_HIP(c, hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream));
-  const int D = 6 * q->W;
-  t.start();
-  static const int wave_prio = getenv("SFMX_BA_NO_WAVE_PRIO") ? 0 : 1;
+// points phase of one iteration (records + contribution rows of every point of the problem)
+static int ba_launch_points(sfmx_ctx* c, sfmx_ba_problem* q, const double* d_poses, double fx, double fy, double cx, double cy, double huber,
+                            int wave_prio, int e_lo = 0, int e_hi = 0x7fffffff) {
   static const char* expand_env = getenv("SFMX_BA_EXPAND");  // "split" / "merged": A/B and tests
   const bool merged = expand_env ? expand_env[0] == 'm' : q->P <= BA_MERGED_EXPAND_MAX_P;
   if (merged) {
@@ -1282,24 +1290,130 @@ static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_
   } else {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_bulk<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx,
                                                                                          fy, cx, cy, huber, q->rec, q->slot_of, nullptr, wave_prio)));
-    SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<q->P, 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib)));
+    SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<q->P, 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib, e_lo, e_hi)));
   }
-  const int nwg = (D * D + D + BAR_COLS - 1) / BAR_COLS;
+  return SFMX_OK;
+}
+// reduction phase over the contribution rows of points [p_lo, p_lo + p_cnt) into S_out | b_out; init: see k_ba_reduce
+// wg_lo / wg_cnt (element-sharded step): only the element blocks [wg_lo, wg_lo + wg_cnt) of BAR_COLS elements each are reduced
+static int ba_element_blocks(const sfmx_ba_problem* q) { const int D = 6 * q->W; return (D * D + D + BAR_COLS - 1) / BAR_COLS; }
+static int ba_launch_reduce(sfmx_ctx* c, sfmx_ba_problem* q, int p_lo, int p_cnt, double lambda, int damp, double* S_out, double* b_out,
+                            const double* init, bool fused_solve, double* host_out, unsigned long long seq, int wave_prio, int wg_lo = 0,
+                            int wg_cnt = -1) {
+  const size_t CS = (size_t)36 * q->W * q->W + 48 * q->W;
+  const double* rows = q->contrib + (size_t)p_lo * CS;
+  const int nwg = wg_cnt >= 0 ? wg_cnt : ba_element_blocks(q);
+  if (nwg == 0) return SFMX_OK;
+  if (wg_cnt >= 0) fused_solve = false;  // a slice of the system: nothing to solve yet
   if (fused_solve && q->W == 6) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                              q->ticket, q->work, host_out, seq, wave_prio)));
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
+                                                                              q->ticket, q->work, host_out, seq, wave_prio, init, wg_lo)));
   } else if (fused_solve && q->W == 10) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 60, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                              q->ticket, q->work, host_out, seq, wave_prio)));
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 60, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
+                                                                              q->ticket, q->work, host_out, seq, wave_prio, init, wg_lo)));
+  } else if (q->P <= BA_MERGED_EXPAND_MAX_P) {
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
+                                                                                   nullptr, nullptr, nullptr, 0, wave_prio, init, wg_lo)));
   } else {
-    if (q->P <= BA_MERGED_EXPAND_MAX_P) {
-      SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                                     nullptr, nullptr, nullptr, 0, wave_prio)));
-    } else {
-      SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, q->P, q->contrib, lambda, damp, q->S, q->b,
-                                                                                     nullptr, nullptr, nullptr, 0, wave_prio)));
-    }
+    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
+                                                                                    nullptr, nullptr, nullptr, 0, wave_prio, init, wg_lo)));
   }
+  return SFMX_OK;
+}
+static const double* ba_stage_poses(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, bool zero_copy_poses, int* rc_out) {
+  *rc_out = SFMX_OK;
+  if (c->h[0].ensure((size_t)q->W * 96) != hipSuccess) { *rc_out = sfmx_fail(c, SFMX_ERR_HIP, "pinned pose staging", hipErrorOutOfMemory); return nullptr; }
+  memcpy(c->h[0].p, poses_wc, (size_t)q->W * 96);
+  // zero_copy_poses: k_ba_points reads the 96 W bytes straight out of the pinned staging buffer (the caller does not touch
+  // it again before it has seen this step's result); otherwise one DMA copy into HBM first
+  if (zero_copy_poses) return c->h[0].as<double>();
+  const hipError_t e = hipMemcpyAsync(q->poses, c->h[0].p, (size_t)q->W * 96, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { *rc_out = sfmx_fail(c, SFMX_ERR_HIP, "hipMemcpyAsync(poses)", e); return nullptr; }
+  return q->poses;
+}
+static int ba_wave_prio() {
+  static const int wave_prio = getenv("SFMX_BA_NO_WAVE_PRIO") ? 0 : 1;
+  return wave_prio;
+}
+static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
+                           double huber, double lambda, int damp, KernelTimer& t, bool zero_copy_poses = false, bool fused_solve = false,
+                           double* host_out = nullptr, unsigned long long seq = 0) {
+  int rc = SFMX_OK;
+  const double* d_poses = ba_stage_poses(c, q, poses_wc, zero_copy_poses, &rc);
+  if (rc) return rc;
+  t.start();
+  rc = ba_launch_points(c, q, d_poses, fx, fy, cx, cy, huber, ba_wave_prio());
+  if (rc) return rc;
+  rc = ba_launch_reduce(c, q, 0, q->P, lambda, damp, q->S, q->b, nullptr, fused_solve, host_out, seq, ba_wave_prio());
+  if (rc) return rc;
+  t.stop();
+  SFMX_HIP(c, hipGetLastError());
+  return SFMX_OK;
+}
+
+// ---- virtual world (TEST MODE, SFMX_VIRTUAL_WORLD=N): what N ranks of the point-sharded step compute, on one GPU ----------
+// The N contiguous point ranges sfmx_shard_range hands out are reduced separately (each chain starts at +0.0, as on its own
+// rank) and combined per element in the order SFMX_VIRTUAL_WORLD_ORDER names -- the association an all-reduce may use:
+//   rank (default)  ((p0 + p1) + p2) + ...          reverse  ((pN-1 + pN-2) + ...) + p0
+//   ring            chunk k of the buffer starts at rank k+1 (ring reduce-scatter)      tree  pairwise ((p0+p1) + (p2+p3)) + ...
+//   relay           no partials at all: shard r continues the running sums of shard r-1 (the sequential reference order)
+__global__ void k_ba_combine_partials(const double* __restrict__ part, int n_ranks, int ne, int order, double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  auto P = [&](int r) { return part[(size_t)r * ne + e]; };
+  double acc;
+  if (order == 1) {
+    acc = P(n_ranks - 1);
+    for (int r = n_ranks - 2; r >= 0; --r) acc = acc + P(r);
+  } else if (order == 2) {
+    const int chunk = (ne + n_ranks - 1) / n_ranks, k = e / chunk;
+    acc = P((k + 1) % n_ranks);
+    for (int s = 2; s <= n_ranks; ++s) acc = acc + P((k + s) % n_ranks);
+  } else if (order == 3) {
+    double v[64];
+    int m = n_ranks < 64 ? n_ranks : 64;
+    for (int r = 0; r < m; ++r) v[r] = P(r);
+    while (m > 1) {
+      int o = 0;
+      for (int r = 0; r + 1 < m; r += 2) v[o++] = v[r] + v[r + 1];
+      if (m & 1) v[o++] = v[m - 1];
+      m = o;
+    }
+    acc = v[0];
+  } else {
+    acc = P(0);
+    for (int r = 1; r < n_ranks; ++r) acc = acc + P(r);
+  }
+  out[e] = acc;
+}
+static int ba_virtual_world() {
+  const char* e = getenv("SFMX_VIRTUAL_WORLD");  // read per call: tests switch it inside one process
+  const int n = e ? atoi(e) : 0;
+  return n > 1 && n <= 64 ? n : 0;
+}
+static int ba_build_virtual_world(sfmx_ctx* c, sfmx_ba_problem* q, int n_ranks, const double* poses_wc, double fx, double fy, double cx,
+                                  double cy, double huber, KernelTimer& t) {
+  const char* oe = getenv("SFMX_VIRTUAL_WORLD_ORDER");
+  const std::string order_s = oe ? oe : "rank";
+  const int order = order_s == "reverse" ? 1 : order_s == "ring" ? 2 : order_s == "tree" ? 3 : order_s == "relay" ? 4 : 0;
+  const int D = 6 * q->W, NE = D * D + D;
+  int rc = SFMX_OK;
+  const double* d_poses = ba_stage_poses(c, q, poses_wc, false, &rc);
+  if (rc) return rc;
+  SFMX_HIP(c, q->bufs[11].ensure((size_t)n_ranks * NE * 8));
+  double* part = q->bufs[11].as<double>();
+  t.start();
+  rc = ba_launch_points(c, q, d_poses, fx, fy, cx, cy, huber, ba_wave_prio());
+  if (rc) return rc;
+  for (int r = 0; r < n_ranks; ++r) {
+    int lo = 0, hi = 0;
+    sfmx_shard_range(q->P, r, n_ranks, &lo, &hi);
+    if (order == 4) rc = ba_launch_reduce(c, q, lo, hi - lo, 0.0, 0, q->S, q->b, r == 0 ? nullptr : q->S, false, nullptr, 0, ba_wave_prio());
+    else rc = ba_launch_reduce(c, q, lo, hi - lo, 0.0, 0, part + (size_t)r * NE, part + (size_t)r * NE + (size_t)D * D, nullptr, false, nullptr, 0,
+                               ba_wave_prio());
+    if (rc) return rc;
+  }
+  if (order != 4) k_ba_combine_partials<<<(NE + 255) / 256, 256, 0, c->stream>>>(part, n_ranks, NE, order, q->S);
   t.stop();
   SFMX_HIP(c, hipGetLastError());
   return SFMX_OK;
@@ -1458,9 +1572,74 @@ int sfmx_ba_step_sharded(sfmx_ctx* c, sfmx_comm* comm, sfmx_ba_problem* q, const
   SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
   const int D = 6 * q->W;
   KernelTimer t(c);
-  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, 0.0, 0, t);  // raw sums of this rank's points
+  const int vworld = (!comm || comm->world <= 1) ? ba_virtual_world() : 0;     // test mode, see ba_build_virtual_world
+  int rc = (vworld > 1 && q->P >= vworld) ? ba_build_virtual_world(c, q, vworld, poses_wc, fx, fy, cx, cy, huber, t)
+                                          : ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, 0.0, 0, t);  // raw sums of this rank's points
   if (rc) return rc;
   rc = sfmx_comm_allreduce_dev(c, comm, q->S, (size_t)D * D + D, 0, 0);        // S | b, in HBM, on the BA stream
+  if (rc) return rc;
+  k_ba_damp_gauge<<<(D + 63) / 64, 64, 0, c->stream>>>(q->S, q->b, D, lambda);
+  int* dstatus = reinterpret_cast<int*>(q->work + D);
+  rc = launch_solve(c, q->S, q->b, D, q->work, dstatus);
+  if (rc) return rc;
+  int status = 0;
+  SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 8));
+  SFMX_HIP(c, hipMemcpyAsync(c->h[1].p, q->work, (size_t)D * 8 + 4, hipMemcpyDeviceToHost, c->stream));  // dx | status
+  SFMX_HIP(c, hipStreamSynchronize(c->stream));
+  c->ba_upload_in_flight = false;
+  t.collect();
+  memcpy(dx_out, c->h[1].p, (size_t)D * 8);
+  memcpy(&status, c->h[1].as<char>() + (size_t)D * 8, 4);
+  return status ? SFMX_ERR_SINGULAR : SFMX_OK;
+}
+
+// Element-sharded BA iteration -- the sharded mode that keeps the reference's arithmetic.  Every rank holds the WHOLE window and
+// computes the per-point records of all points (replicated: 10 % of an iteration at C4 size); rank r then forms and reduces only
+// ITS contiguous slice of the element blocks of S | b, each element's chain over all points in reference order, and contributes
+// +0.0 everywhere else.  The all-reduce(sum) adds zeros to every element (x + 0.0 == x; the running sums are never -0.0), so the
+// system -- and dx -- is bit-identical to sfmx_ba_step on one GPU at any world size and for any reduction order RCCL picks.
+// (Point sharding, sfmx_ba_step_sharded, regroups the addends of every element; on this BA that rounding difference is
+// amplified to a different trajectory within tens of keyframes -- tools/virtual_world_probe.py)
+int sfmx_ba_step_sharded_elements(sfmx_ctx* c, sfmx_comm* comm, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx,
+                                  double cy, double huber, double lambda, double* dx_out) {
+  SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
+  const int D = 6 * q->W, NE = D * D + D;
+  const bool real = comm && comm->world > 1;
+  const int vworld = real ? 0 : ba_virtual_world();  // test mode: the N slices formed one after the other on this GPU
+  const int world = real ? comm->world : (vworld > 1 ? vworld : 1);
+  const int nblk = ba_element_blocks(q);
+  KernelTimer t(c);
+  int rc = SFMX_OK;
+  const double* d_poses = ba_stage_poses(c, q, poses_wc, false, &rc);
+  if (rc) return rc;
+  double* part = nullptr;
+  if (vworld > 1) {
+    SFMX_HIP(c, q->bufs[11].ensure((size_t)vworld * NE * 8));
+    part = q->bufs[11].as<double>();
+    SFMX_HIP(c, hipMemsetAsync(part, 0, (size_t)vworld * NE * 8, c->stream));
+  }
+  t.start();
+  for (int r = 0; r < (vworld > 1 ? vworld : 1); ++r) {
+    const int rank = real ? comm->rank : r;
+    int b_lo = 0, b_hi = nblk;
+    sfmx_shard_range(nblk, rank, world, &b_lo, &b_hi);
+    const int e_lo = b_lo * BAR_COLS, e_hi = b_hi * BAR_COLS < NE ? b_hi * BAR_COLS : NE;
+    double* S_out = part ? part + (size_t)r * NE : q->S;
+    if (!part && world > 1) SFMX_HIP(c, hipMemsetAsync(q->S, 0, (size_t)NE * 8, c->stream));  // S | b contiguous: +0.0 outside the slice
+    rc = ba_launch_points(c, q, d_poses, fx, fy, cx, cy, huber, ba_wave_prio(), e_lo, e_hi);
+    if (rc) return rc;
+    rc = ba_launch_reduce(c, q, 0, q->P, 0.0, 0, S_out, S_out + (size_t)D * D, nullptr, false, nullptr, 0, ba_wave_prio(), b_lo, b_hi - b_lo);
+    if (rc) return rc;
+  }
+  if (part) {
+    const char* oe = getenv("SFMX_VIRTUAL_WORLD_ORDER");
+    const std::string order_s = oe ? oe : "rank";
+    const int order = order_s == "reverse" ? 1 : order_s == "ring" ? 2 : order_s == "tree" ? 3 : 0;
+    k_ba_combine_partials<<<(NE + 255) / 256, 256, 0, c->stream>>>(part, vworld, NE, order, q->S);
+  }
+  t.stop();
+  SFMX_HIP(c, hipGetLastError());
+  rc = sfmx_comm_allreduce_dev(c, comm, q->S, (size_t)NE, 0, 0);  // S | b, in HBM, on the BA stream
   if (rc) return rc;
   k_ba_damp_gauge<<<(D + 63) / 64, 64, 0, c->stream>>>(q->S, q->b, D, lambda);
   int* dstatus = reinterpret_cast<int*>(q->work + D);

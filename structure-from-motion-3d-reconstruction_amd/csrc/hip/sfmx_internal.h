@@ -12,12 +12,18 @@
 
 #define SFMX_MAX_LEVELS 8
 
+// Grow-only device / pinned slabs.  Growing never frees: hipFree / hipHostFree wait for EVERY stream of the device, and a
+// lane that waits there while another lane's RCCL collective is in flight (blocked on a peer whose own lane waits the same way)
+// is a deadlock across ranks.  The outgrown block is parked and released with the buffer (growth is geometric, so the parked
+// blocks add up to less than four times the final size).
+#include <vector>
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  std::vector<void*> parked;
   hipError_t ensure(size_t n) {
     if (n <= cap) return hipSuccess;
-    if (p) (void)hipFree(p);
+    if (p) parked.push_back(p);
     p = nullptr;
     cap = 0;
     size_t want = n < 4096 ? 4096 : n + n / 4;
@@ -27,27 +33,34 @@ struct DevBuf {
   }
   void release() {
     if (p) (void)hipFree(p);
+    for (void* q : parked) (void)hipFree(q);
+    parked.clear();
     p = nullptr;
     cap = 0;
   }
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Pinned host memory that kernels read and write directly (track positions, BA poses, polled result blocks): fine-grained
+// coherent and mapped, requested explicitly rather than through the runtime's default for flags == 0.
 struct PinBuf {
   void* p = nullptr;
   size_t cap = 0;
+  std::vector<void*> parked;
   hipError_t ensure(size_t n) {
     if (n <= cap) return hipSuccess;
-    if (p) (void)hipHostFree(p);
+    if (p) parked.push_back(p);
     p = nullptr;
     cap = 0;
     size_t want = n < 4096 ? 4096 : n + n / 4;
-    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocCoherent | hipHostMallocMapped);
     if (e == hipSuccess) cap = want;
     return e;
   }
   void release() {
     if (p) (void)hipHostFree(p);
+    for (void* q : parked) (void)hipHostFree(q);
+    parked.clear();
     p = nullptr;
     cap = 0;
   }

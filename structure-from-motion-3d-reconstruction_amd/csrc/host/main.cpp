@@ -252,34 +252,56 @@ int main(int argc, char** argv) {
     if (rc != SFMX_OK) throw std::runtime_error("no usable MI355X (gfx950) device: sfmx_ctx_create failed (there is no CPU fallback)");
     struct CtxGuard { sfmx_ctx* c; ~CtxGuard() { sfmx_ctx_destroy(c); } } guard{ctx};
     struct Comms {
-      sfmx_comm* c[4] = {nullptr, nullptr, nullptr, nullptr};
+      sfmx_comm* c[2] = {nullptr, nullptr};  // BA lane, RANSAC merges of the geometry thread (pipeline.hpp: PipelineConfig)
       ~Comms() { for (sfmx_comm* m : c) sfmx_comm_destroy(m); }
     } comms;
     if (dist_world > 1) {
       const char* idf = std::getenv("SFMX_DIST_ID_FILE");
       if (!idf || dist_rank < 0 || dist_rank >= dist_world) throw std::runtime_error("SFMX_DIST_WORLD needs SFMX_DIST_RANK in range and SFMX_DIST_ID_FILE");
-      std::string ids((size_t)4 * SFMX_COMM_ID_BYTES, '\0');
+      // File = 16-byte header {"SFMXID02", run id} + the unique ids.  The run id (FNV-1a of SFMX_DIST_RUN_ID, which the launcher
+      // sets to something fresh per launch) keeps a rank from picking up the file a PREVIOUS launch left at the same path --
+      // mismatched ids would block ncclCommInitRank forever.  Without a run id a file older than the waiting time is refused.
+      std::uint64_t run_id = 0;
+      if (const char* rid = std::getenv("SFMX_DIST_RUN_ID")) {
+        run_id = 1469598103934665603ull;
+        for (const char* q = rid; *q; ++q) run_id = (run_id ^ (unsigned char)*q) * 1099511628211ull;
+        if (run_id == 0) run_id = 1;
+      }
+      constexpr int kComms = 2;
+      constexpr size_t kHeader = 16;
+      std::string blob(kHeader + (size_t)kComms * SFMX_COMM_ID_BYTES, '\0');
+      std::memcpy(&blob[0], "SFMXID02", 8);
+      std::memcpy(&blob[8], &run_id, 8);
       if (dist_rank == 0) {
-        for (int k = 0; k < 4; k++)
-          if (sfmx_comm_get_unique_id(&ids[(size_t)k * SFMX_COMM_ID_BYTES]) != SFMX_OK) throw std::runtime_error("RCCL is not available (sfmx_comm_get_unique_id)");
+        std::error_code ec;
+        fs::remove(idf, ec);  // whatever an earlier launch left behind
+        for (int k = 0; k < kComms; k++)
+          if (sfmx_comm_get_unique_id(&blob[kHeader + (size_t)k * SFMX_COMM_ID_BYTES]) != SFMX_OK) throw std::runtime_error("RCCL is not available (sfmx_comm_get_unique_id)");
         const std::string tmp = std::string(idf) + ".tmp";
-        { std::ofstream f(tmp, std::ios::binary); f.write(ids.data(), (std::streamsize)ids.size()); }
+        { std::ofstream f(tmp, std::ios::binary); f.write(blob.data(), (std::streamsize)blob.size()); }
         fs::rename(tmp, idf);
       } else {
+        const auto started = fs::file_time_type::clock::now();
+        std::string got(blob.size(), '\0');
         for (int tries = 0;; ++tries) {  // wait for rank 0 (up to two minutes)
           std::ifstream f(idf, std::ios::binary);
-          if (f && f.read(&ids[0], (std::streamsize)ids.size())) break;
-          if (tries > 1200) throw std::runtime_error(std::string("timed out waiting for ") + idf);
+          bool ok = f && f.read(&got[0], (std::streamsize)got.size()) && std::memcmp(got.data(), blob.data(), kHeader) == 0;
+          if (ok && run_id == 0) {  // no run id to tell launches apart: a file older than the two minutes a rank waits is stale
+            std::error_code ec;
+            const auto mt = fs::last_write_time(idf, ec);
+            ok = !ec && mt + std::chrono::seconds(120) >= started;
+          }
+          if (ok) break;
+          if (tries > 1200) throw std::runtime_error(std::string("timed out waiting for ") + idf + " (missing, stale, or written for another SFMX_DIST_RUN_ID)");
           std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
+        blob = got;
       }
-      for (int k = 0; k < 4; k++)
-        if (sfmx_comm_create(device, &ids[(size_t)k * SFMX_COMM_ID_BYTES], dist_rank, dist_world, &comms.c[k]) != SFMX_OK)
+      for (int k = 0; k < kComms; k++)
+        if (sfmx_comm_create(device, &blob[kHeader + (size_t)k * SFMX_COMM_ID_BYTES], dist_rank, dist_world, &comms.c[k]) != SFMX_OK)
           throw std::runtime_error("sfmx_comm_create failed (RCCL)");
       pc.comm_ba = comms.c[0];
-      pc.comm_ransac_a = comms.c[1];
-      pc.comm_ransac_c = comms.c[2];
-      pc.comm_ransac_e = comms.c[3];
+      pc.comm_ransac = comms.c[1];
     }
     const bool speaker = dist_rank == 0;  // every rank computes the same result; one of them reports it
 

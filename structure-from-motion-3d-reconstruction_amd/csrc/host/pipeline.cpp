@@ -632,14 +632,26 @@ StepOut GpuTracker::step(FrameSource& src, int fi) {
 }
 
 // ------------------------------------------------------------------------------------------ RANSAC
-std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
-                                         double thr, int min_inliers, StageClock* clk, sfmx_comm* comm) {
-  if (pi.size() < 8) return std::nullopt;  // T:648
+// find_E_ransac (T:646-761) in two halves.  ransac_local: this rank's share of the hypothesis loop (T:664-677) -- the EXACT
+// winner (count, lowest iteration, E, mask) of its contiguous iteration range, no communication.  ransac_merge: the ranks'
+// winners -> the call's winner (all-reduce(max) of the packed key, the winner's E as raw bits), then the decomposition
+// (T:680-760).  A pipeline runs the first half on whatever lane has the data and the second on the geometry thread, where
+// the calls are consumed in program order: every rank issues the collectives of its RANSAC communicator in the same order.
+RansacLocal ransac_local(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters, double thr,
+                         int min_inliers, StageClock* clk, int rank, int world) {
+  RansacLocal out;
+  out.thr = thr;
+  out.min_inliers = min_inliers;
+  if (pi.size() < 8) { out.none = true; return out; }  // T:648
   const auto t0 = Clock::now();
   Mat3 Kinv;
   if (!invert_K(K, Kinv)) throw std::runtime_error("Singular K");  // T:474
   const int n = (int)pi.size();
-  std::vector<double> xi((size_t)2 * n), xj((size_t)2 * n);
+  out.n = n;
+  std::vector<double>& xi = out.xi;
+  std::vector<double>& xj = out.xj;
+  xi.resize((size_t)2 * n);
+  xj.resize((size_t)2 * n);
   for (int i = 0; i < n; i++) {
     const V2 a = norm_point(Kinv, pi[(size_t)i]), b = norm_point(Kinv, pj[(size_t)i]);
     xi[2 * (size_t)i] = a.x; xi[2 * (size_t)i + 1] = a.y;
@@ -661,10 +673,10 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
     size_t pos = 0;
     bool exhausted = false;
     const std::uint32_t range = (std::uint32_t)n;
-    const std::uint32_t thr = (0u - range) % range;
+    const std::uint32_t rej = (0u - range) % range;
     for (size_t k = 0; k < idx8.size() && !exhausted; k++) {
       std::uint64_t prod = (std::uint64_t)raw[pos++] * range;
-      while ((std::uint32_t)prod < thr) {
+      while ((std::uint32_t)prod < rej) {
         if (pos >= raw.size()) { exhausted = true; break; }
         prod = (std::uint64_t)raw[pos++] * range;
       }
@@ -676,14 +688,12 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
       for (size_t k = 0; k < idx8.size(); k++) idx8[k] = rng.below(range);
     }
   }
-  if (iters <= 0) return std::nullopt;
+  if (iters <= 0) { out.none = true; return out; }
   if (clk) clk->r_pre += since(t0);
   const auto tg0 = Clock::now();
-  // hypothesis sharding: this rank scores iterations [h0, h1) of the common sample stream; everything below works on the
-  // local range with GLOBAL iteration numbers and is merged with three tiny collectives (one rank: h0 = 0, h1 = iters)
+  // hypothesis sharding: this rank scores iterations [h0, h1) of the common sample stream, with GLOBAL iteration numbers
   int h0 = 0, h1 = iters;
-  const bool sharded = comm && sfmx_comm_world(comm) > 1;
-  if (sharded) sfmx_shard_range(iters, sfmx_comm_rank(comm), sfmx_comm_world(comm), &h0, &h1);
+  if (world > 1) sfmx_shard_range(iters, rank, world, &h0, &h1);
   const int hl = h1 - h0;
   std::vector<std::int32_t> counts((size_t)iters, 0), lo((size_t)iters, 0), hi((size_t)iters, 0);
   std::int32_t best_iter = -1, best_count = 0;
@@ -698,25 +708,17 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
     clk->r_gpu += since(tg0);
   }
   const auto tv0 = Clock::now();
-  // The library reports, per iteration, a count and certified bounds lo <= reference count <= hi (include/sfmx.h):
-  // lo == hi where the hypothesis is the exact host one (repeated-index / ill-conditioned octets) or where no point
-  // lies inside the rounding band around thr.  The reference's winner is the LOWEST iteration with the maximal count
-  // (strict '>' at T:673); only iterations with hi >= max(lo) can be it.  Of those, the uncertain ones (lo < hi) are
-  // re-derived exactly here -- E with the platform libm, mask from that E on the device -- and so is the winner, whose
-  // E and mask are what leaves this function.
-  std::optional<RelPose> result;
+  // The library reports, per iteration, a count and bounds lo <= reference count <= hi (include/sfmx.h): lo == hi where the
+  // hypothesis is the exact host one (repeated-index / ill-conditioned octets) or where no point lies inside the rounding
+  // band around thr.  The reference's winner is the LOWEST iteration with the maximal count (strict '>' at T:673); only
+  // iterations with hi >= max(lo) can be it.  Of those, the uncertain ones (lo < hi) are re-derived exactly here -- E with
+  // the platform libm, mask from that E on the device -- and so is the winner, whose E and mask are what leaves this function.
   int best_lo = 0, best_hi = 0;
   for (int it = h0; it < h1; ++it) { best_lo = std::max(best_lo, lo[(size_t)it]); best_hi = std::max(best_hi, hi[(size_t)it]); }
-  if (sharded) {  // the bounds every rank prunes with are the global ones
-    double b2[2] = {(double)best_lo, (double)best_hi};
-    check(ctx, sfmx_comm_allreduce_f64(ctx, comm, b2, 2, 1), "allreduce(max) of the count bounds");
-    best_lo = (int)b2[0];
-    best_hi = (int)b2[1];
-  }
   if (best_hi > 0 && best_hi >= min_inliers) {
-    int win_iter = -1, win_count = -1;
-    Mat3 winE;
-    std::vector<std::uint8_t> mask((size_t)n), win_mask;
+    int& win_iter = out.win_iter;
+    int& win_count = out.win_count;
+    std::vector<std::uint8_t> mask((size_t)n);
     auto verify = [&](int it) {
       const Mat3 E = eight_point_E(xi.data(), xj.data(), &idx8[(size_t)8 * it]);
       std::int32_t cnt = 0;
@@ -725,8 +727,8 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
       if (cnt > win_count || (cnt == win_count && it < win_iter)) {
         win_count = cnt;
         win_iter = it;
-        winE = E;
-        win_mask = mask;
+        out.winE = E;
+        out.win_mask = mask;
       }
       return cnt;
     };
@@ -738,51 +740,66 @@ std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std
       else if (counts[(size_t)it] > cert_count) { cert_count = counts[(size_t)it]; cert_iter = it; }
     }
     // pass 2: the best certain candidate beats (or ties earlier than) every verified one?  Then it is this rank's winner and
-    // needs its exact E and mask; its exact count must equal the certified one.
+    // needs its exact E and mask; its exact count must equal the bounded one.
     if (cert_iter >= 0 && (cert_count > win_count || (cert_count == win_count && cert_iter < win_iter))) {
       const int cnt = verify(cert_iter);
       if (cnt != cert_count) {
-        // A certificate did not hold (never observed).  Parity first: fall back to exact counts of every candidate.
+        // A bound did not hold (never observed), so none of this call's bounds is trusted any more.  Parity first: exact counts
+        // of EVERY iteration that has an inlier at all.
         if (clk) clk->ransac_cert_misses++;
         win_iter = -1; win_count = -1;
         for (int it = h0; it < h1; ++it)
-          if (hi[(size_t)it] >= best_lo - 4 && hi[(size_t)it] > 0) verify(it);
+          if (hi[(size_t)it] > 0) verify(it);
       }
     }
-    if (sharded) {
-      // global winner: max count, lowest iteration (T:673) over the ranks' exact local winners; its E travels as raw bits
-      // (max over {bits, 0, 0, ...}: exact, signs of zeros included), its mask is recomputed from that E by every rank
-      std::uint64_t key = win_iter >= 0 ? (((std::uint64_t)(std::uint32_t)win_count << 32) | (std::uint64_t)(0x7fffffff - win_iter)) : 0;
-      const std::uint64_t mine = key;
-      check(ctx, sfmx_comm_allreduce_u64_max(ctx, comm, &key, 1), "allreduce(max) of the winner key");
-      std::uint64_t ebits[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (key != 0 && key == mine) std::memcpy(ebits, winE.a, 72);
-      check(ctx, sfmx_comm_allreduce_u64_max(ctx, comm, ebits, 9), "allreduce of the winner's E");
-      if (key == 0) { win_iter = -1; win_count = -1; }
-      else if (key != mine) {
-        win_count = (int)(key >> 32);
-        win_iter = 0x7fffffff - (int)(key & 0xffffffffull);
-        std::memcpy(winE.a, ebits, 72);
-        std::int32_t cnt = 0;
-        check(ctx, sfmx_sampson_mask(ctx, xi.data(), xj.data(), n, winE.a, thr, mask.data(), &cnt), "sampson_mask");
-        win_mask = mask;
-      }
-    }
-    if (clk) clk->r_verify += since(tv0);
-    const auto td0 = Clock::now();
-    if (win_iter >= 0 && win_count >= min_inliers) {  // T:678
-      RelPose rp;
-      rp.best_iter = win_iter;
-      for (int i = 0; i < n; i++)
-        if (win_mask[(size_t)i]) rp.inliers.push_back(i);
-      decompose_E(winE, xi.data(), xj.data(), rp.inliers, rp.R_ji, rp.t_ji, nullptr,
-                  [](int n, const std::function<void(int)>& f) { ThreadPool::instance().parallel_for(n, f, 8); });
-      result = std::move(rp);
-    }
-    if (clk) clk->r_decomp += since(td0);
   }
-  if (clk) clk->ransac += since(t0);
+  if (clk) { clk->r_verify += since(tv0); clk->ransac += since(t0); }
+  return out;
+}
+
+std::optional<RelPose> ransac_merge(sfmx_ctx* ctx, sfmx_comm* comm, RansacLocal&& loc, StageClock* clk) {
+  if (loc.none) return std::nullopt;
+  const auto t0 = Clock::now();
+  std::optional<RelPose> result;
+  const int n = loc.n;
+  int win_iter = loc.win_iter, win_count = loc.win_count;
+  if (comm && sfmx_comm_world(comm) > 1) {
+    // global winner: max count, lowest iteration (T:673) over the ranks' exact local winners; its E travels as raw bits
+    // (max over {bits, 0, 0, ...}: exact, signs of zeros included), its mask is recomputed from that E by every other rank
+    std::uint64_t key = win_iter >= 0 ? (((std::uint64_t)(std::uint32_t)win_count << 32) | (std::uint64_t)(0x7fffffff - win_iter)) : 0;
+    const std::uint64_t mine = key;
+    check(ctx, sfmx_comm_allreduce_u64_max(ctx, comm, &key, 1), "allreduce(max) of the winner key");
+    std::uint64_t ebits[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (key != 0 && key == mine) std::memcpy(ebits, loc.winE.a, 72);
+    if (key != 0) check(ctx, sfmx_comm_allreduce_u64_max(ctx, comm, ebits, 9), "allreduce of the winner's E");  // key is global: every rank skips or none
+    if (key == 0) { win_iter = -1; win_count = -1; }
+    else if (key != mine) {
+      win_count = (int)(key >> 32);
+      win_iter = 0x7fffffff - (int)(key & 0xffffffffull);
+      std::memcpy(loc.winE.a, ebits, 72);
+      if (win_count >= loc.min_inliers) {  // otherwise the gate below drops the result and the mask is never read
+        std::int32_t cnt = 0;
+        loc.win_mask.resize((size_t)n);
+        check(ctx, sfmx_sampson_mask(ctx, loc.xi.data(), loc.xj.data(), n, loc.winE.a, loc.thr, loc.win_mask.data(), &cnt), "sampson_mask");
+      }
+    }
+  }
+  if (win_iter >= 0 && win_count >= loc.min_inliers) {  // T:678
+    RelPose rp;
+    rp.best_iter = win_iter;
+    for (int i = 0; i < n; i++)
+      if (loc.win_mask[(size_t)i]) rp.inliers.push_back(i);
+    decompose_E(loc.winE, loc.xi.data(), loc.xj.data(), rp.inliers, rp.R_ji, rp.t_ji, nullptr,
+                [](int n, const std::function<void(int)>& f) { ThreadPool::instance().parallel_for(n, f, 8); });
+    result = std::move(rp);
+  }
+  if (clk) { clk->r_decomp += since(t0); clk->ransac += since(t0); }
   return result;
+}
+
+std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
+                                         double thr, int min_inliers, StageClock* clk, sfmx_comm* comm) {
+  return ransac_merge(ctx, comm, ransac_local(ctx, K, pi, pj, iters, thr, min_inliers, clk, sfmx_comm_rank(comm), sfmx_comm_world(comm)), clk);
 }
 
 // ------------------------------------------------------------------------------------------ map
@@ -860,9 +877,18 @@ void GpuBundleAdjuster::solve(BaJob& job) {
   const auto t0 = Clock::now();
   const int W = job.W, P = job.P, D = 6 * W;
   const Mat3& K = job.K;
-  // Point sharding: this rank keeps the contiguous range [lo, hi) of the window's points (reference order) and its
-  // observation lists; with fewer points than ranks every rank runs the whole (tiny) problem itself, no collective.
-  const bool sharded = comm_ && sfmx_comm_world(comm_) > 1 && P >= sfmx_comm_world(comm_);
+  // Multi-GPU run: by default the ELEMENTS of S | b are sharded (sfmx_ba_step_sharded_elements: every rank holds the whole
+  // window, results bit-identical to one GPU).  SFMX_BA_SHARD=points selects point sharding instead (tolerance mode: this rank
+  // keeps the contiguous range [lo, hi) of the window's points in reference order; with fewer points than ranks every rank
+  // runs the whole tiny problem itself, no collective).
+  // SFMX_VIRTUAL_WORLD=N (test mode, one rank): the same two entry points form what N ranks would on this one GPU.
+  const bool multi = comm_ && sfmx_comm_world(comm_) > 1;
+  const char* vw = std::getenv("SFMX_VIRTUAL_WORLD");
+  const bool virtual_world = !multi && vw && std::atoi(vw) > 1;
+  const char* sm = std::getenv("SFMX_BA_SHARD");
+  const bool by_points = sm && std::string(sm) == "points";
+  const bool sharded = multi && by_points && P >= sfmx_comm_world(comm_);
+  const bool by_elements = (multi || virtual_world) && !by_points;
   const double* Xp = job.X.data();
   const std::int32_t* optr = job.optr.data();
   const std::int32_t* oli = job.oli.data();
@@ -893,9 +919,11 @@ void GpuBundleAdjuster::solve(BaJob& job) {
       std::memcpy(&poses[(size_t)12 * li], R.a, 72);
       poses[(size_t)12 * li + 9] = t.x; poses[(size_t)12 * li + 10] = t.y; poses[(size_t)12 * li + 11] = t.z;
     }
-    const int rc = sharded ? sfmx_ba_step_sharded(ctx_, comm_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), job.cfg.huber_delta,
-                                                  job.cfg.lambda, dx.data())
-                           : sfmx_ba_step(ctx_, prob_, poses.data(), K(0, 0), K(1, 1), K(0, 2), K(1, 2), job.cfg.huber_delta, job.cfg.lambda, dx.data());
+    const double fx = K(0, 0), fy = K(1, 1), cx = K(0, 2), cy = K(1, 2);
+    int rc;
+    if (by_elements) rc = sfmx_ba_step_sharded_elements(ctx_, multi ? comm_ : nullptr, prob_, poses.data(), fx, fy, cx, cy, job.cfg.huber_delta, job.cfg.lambda, dx.data());
+    else if (sharded || virtual_world) rc = sfmx_ba_step_sharded(ctx_, sharded ? comm_ : nullptr, prob_, poses.data(), fx, fy, cx, cy, job.cfg.huber_delta, job.cfg.lambda, dx.data());
+    else rc = sfmx_ba_step(ctx_, prob_, poses.data(), fx, fy, cx, cy, job.cfg.huber_delta, job.cfg.lambda, dx.data());
     if (clk_) { clk_->ba_kernel_us += sfmx_last_kernel_us(ctx_); clk_->ba_iters++; }
     if (rc == SFMX_ERR_SINGULAR) break;  // T:1076-1078: ill-conditioned -> skip the rest of BA
     check(ctx_, rc, "ba_step");
@@ -1301,19 +1329,39 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   if (track_lane && !std::getenv("SFMX_NO_RANSAC_LANE"))
     lane_a = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A);
   if (lane_a && sfmx_get_timing(ctx)) (void)sfmx_set_timing(lane_a->ctx(), 1);
+  // multi-GPU run: a lane computes this rank's half of a RANSAC call (ransac_local), the geometry thread merges it with the
+  // other ranks' where it consumes the result -- the one place whose order is the same on every rank
+  sfmx_comm* const rcomm = cfg.comm_ransac;
+  const int r_rank = sfmx_comm_rank(rcomm), r_world = sfmx_comm_world(rcomm);
+  const bool r_sharded = r_world > 1;
+  auto ransac_ahead = [r_rank, r_world, r_sharded](sfmx_ctx* c, const Mat3& Km, const std::vector<V2>& a, const std::vector<V2>& b, int iters,
+                                                   double thr, int min_inl, StageClock* ck) {
+    auto out = std::make_shared<RansacAhead>();
+    out->local = ransac_local(c, Km, a, b, iters, thr, min_inl, ck, r_rank, r_world);
+    out->merged = !r_sharded;
+    if (out->merged) out->rel = ransac_merge(c, nullptr, std::move(out->local), ck);
+    return out;
+  };
+  auto ransac_finish = [&](RansacAhead& ra) -> std::optional<RelPose> {  // geometry thread only
+    if (!ra.merged) {
+      ra.rel = ransac_merge(ctx, rcomm, std::move(ra.local), &clk);
+      ra.merged = true;
+    }
+    return ra.rel;
+  };
   std::function<void(FramePacket&)> on_packet;
   if (lane_a)
-    on_packet = [&lane_a, &lane_a_clk, K, comm_a = cfg.comm_ransac_a](FramePacket& p) {
+    on_packet = [&lane_a, &lane_a_clk, K, ransac_ahead](FramePacket& p) {
       if (p.step.prev_pts.empty()) return;
-      auto prom = std::make_shared<std::promise<std::optional<RelPose>>>();
+      auto prom = std::make_shared<std::promise<std::shared_ptr<RansacAhead>>>();
       p.rel = prom->get_future().share();
       auto pi = std::make_shared<const std::vector<V2>>(p.step.prev_pts);
       auto pj = std::make_shared<const std::vector<V2>>(p.step.cur_pts);
       AsyncLane* la = lane_a.get();
       StageClock* ck = &lane_a_clk;
-      la->submit([prom, pi, pj, la, ck, K, comm_a]() {
+      la->submit([prom, pi, pj, la, ck, K, ransac_ahead]() {
         try {
-          prom->set_value(find_E_ransac_gpu(la->ctx(), K, *pi, *pj, 2500, 1e-3, 60, ck, comm_a));
+          prom->set_value(ransac_ahead(la->ctx(), K, *pi, *pj, 2500, 1e-3, 60, ck));
         } catch (...) {
           prom->set_exception(std::current_exception());
         }
@@ -1349,7 +1397,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   if (use_lane) {
     lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_B", 0), ContextPool::LANE_B);
     lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_C", 0), ContextPool::LANE_C);
-    if (!std::getenv("SFMX_NO_EDGE_LANE") && (cfg.comm_ransac_c == nullptr || cfg.comm_ransac_e != nullptr))
+    if (!std::getenv("SFMX_NO_EDGE_LANE"))
       lane_e = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_E", 0), ContextPool::LANE_E);
   }
   if (sfmx_get_timing(ctx)) {  // per-kernel event timing is inherited by the helper contexts
@@ -1364,14 +1412,13 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   AsyncLane* edge_lane = lane_e ? lane_e.get() : lane_c.get();  // where the keyframe->keyframe RANSAC runs
   sfmx_ctx* ectx = lane_e ? lane_e->ctx() : cctx;
   StageClock* eclk = lane_e ? &lane_e_clk : cclk;
-  sfmx_comm* ecomm = lane_e ? cfg.comm_ransac_e : cfg.comm_ransac_c;
   GpuBundleAdjuster ba(bctx, bclk, cfg.comm_ba, lane ? &lane->pooled()->ba : nullptr);
   sfmx_pyramid* old_pyr_c = nullptr;  // lane C's copy of the old keyframe image
   struct PyrGuardC { sfmx_ctx* c; sfmx_pyramid** p; ~PyrGuardC() { if (*p) sfmx_pyramid_destroy(c, *p); } } guard_c{cctx, &old_pyr_c};
-  struct PendingEdge { int i, j; std::optional<RelPose> rel; };
+  struct PendingEdge { int i, j; std::shared_ptr<RansacAhead> ra; };
   std::deque<PendingEdge> pending_edges;
   BaJob pending_ba;
-  struct PendingLoop { bool active = false; int frame = -1, old_kf = -1, new_kf = -1; std::optional<RelPose> rel; } pending_loop;
+  struct PendingLoop { bool active = false; int frame = -1, old_kf = -1, new_kf = -1; std::shared_ptr<RansacAhead> ra; std::optional<RelPose> rel; } pending_loop;
   struct LaneGuard {  // declared after everything the lanes' tasks reference: drained first when unwinding
     AsyncLane *l, *m, *e;
     ~LaneGuard() {
@@ -1397,8 +1444,11 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     const auto tj = Clock::now();
     if (edge_lane) edge_lane->wait();
     clk.join_wait += since(tj);
-    for (PendingEdge& pe : pending_edges)
-      if (pe.rel) edges.push_back(PGEdge{pe.i, pe.j, pe.rel->R_ji, pe.rel->t_ji, (int)pe.rel->inliers.size(), false});
+    for (PendingEdge& pe : pending_edges) {  // keyframe order = the order every rank merges them in
+      if (!pe.ra) continue;
+      const std::optional<RelPose> rel = ransac_finish(*pe.ra);
+      if (rel) edges.push_back(PGEdge{pe.i, pe.j, rel->R_ji, rel->t_ji, (int)rel->inliers.size(), false});
+    }
     pending_edges.clear();
   };
   auto join_c = [&]() -> bool {
@@ -1406,8 +1456,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     if (lane_c) lane_c->wait();
     clk.join_wait += since(tj);
     if (pending_loop.active) {  // verdict of the loop-closure verification of the last keyframe (T:1858)
-      const PendingLoop pl = pending_loop;
+      PendingLoop pl = pending_loop;
       pending_loop = PendingLoop{};
+      if (pl.ra) pl.rel = ransac_finish(*pl.ra);
       if (pl.rel && (int)pl.rel->inliers.size() >= 100) accepted_loop = pl;
     }
     return accepted_loop.has_value();
@@ -1493,8 +1544,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     const std::vector<V2>& p_j = step.cur_pts;
     const auto tm1 = Clock::now();
     std::optional<RelPose> rel;
-    if (pkt.rel.valid()) rel = pkt.rel.get();                                     // T:1739, started ahead on lane A
-    else rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk, cfg.comm_ransac_a);
+    if (pkt.rel.valid()) rel = ransac_finish(*pkt.rel.get());                     // T:1739, started ahead on lane A
+    else rel = find_E_ransac_gpu(ctx, K, p_i, p_j, 2500, 1e-3, 60, &clk, rcomm);
     clk.m_ransac += since(tm1);
     const auto tp0 = Clock::now();
     int inliers = 0;
@@ -1550,10 +1601,10 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
         }
         clk.bookkeeping += since(tb0);
         if (ei.size() >= 80) {
-          pending_edges.push_back(PendingEdge{prev_kf.kf_id, kf.kf_id, std::nullopt});
+          pending_edges.push_back(PendingEdge{prev_kf.kf_id, kf.kf_id, nullptr});
           PendingEdge* slot = &pending_edges.back();  // std::deque: stays valid while later edges are appended
-          auto task = [slot, ectx, eclk, K, ecomm, ei = std::move(ei), ej = std::move(ej)]() {
-            slot->rel = find_E_ransac_gpu(ectx, K, ei, ej, 2500, 1e-3, 60, eclk, ecomm);
+          auto task = [slot, ectx, eclk, K, ransac_ahead, ei = std::move(ei), ej = std::move(ej)]() {
+            slot->ra = ransac_ahead(ectx, K, ei, ej, 2500, 1e-3, 60, eclk);
           };
           if (edge_lane) edge_lane->submit(std::move(task));
           else task();
@@ -1643,7 +1694,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           }
           clk.shi += since(ts0);
         }
-        pending_loop = PendingLoop{true, fi, old_kf.kf_id, new_kf_id, std::nullopt};
+        pending_loop = PendingLoop{true, fi, old_kf.kf_id, new_kf_id, nullptr, std::nullopt};
         const int old_frame = old_kf.frame_idx;
         const sfmx_pyramid* cur_pyr = pkt.pyr;  // not released to the tracker lane while this verification is pending
         auto verify = [&, lc, old_frame, cur_pyr, pts0 = std::move(pts0)]() {
@@ -1660,7 +1711,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
             li.push_back(pts0[i]);
             lj.push_back(fwd[i]);
           }
-          if (li.size() >= 120) pending_loop.rel = find_E_ransac_gpu(cctx, K, li, lj, 4000, 2e-3, 80, cclk, cfg.comm_ransac_c);
+          if (li.size() >= 120) pending_loop.ra = ransac_ahead(cctx, K, li, lj, 4000, 2e-3, 80, cclk);
         };
         if (lane_c) lane_c->submit(std::move(verify));
         else { verify(); join_lane(); }
@@ -1789,7 +1840,7 @@ struct sfmx_pipeline_cfg {
   double kf_parallax_px;
   int ba_window, ba_iters, ba_max_points;
   double ba_huber, ba_lambda;
-  sfmx_comm *comm_ba, *comm_ransac_a, *comm_ransac_c, *comm_ransac_e;  // multi-GPU mode (PipelineConfig); null = unsharded
+  sfmx_comm *comm_ba, *comm_ransac;  // multi-GPU mode (PipelineConfig); null = unsharded
 };
 struct sfmx_pipeline_stats {
   int n_keyframes, n_points, n_edges, n_frames;
@@ -1837,7 +1888,7 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     pc.kf_min_gap = cfg->kf_min_gap; pc.kf_min_inliers = cfg->kf_min_inliers; pc.kf_parallax_px = cfg->kf_parallax_px;
     pc.ba.window = cfg->ba_window; pc.ba.iters = cfg->ba_iters; pc.ba.max_points = cfg->ba_max_points;
     pc.ba.huber_delta = cfg->ba_huber; pc.ba.lambda = cfg->ba_lambda;
-    pc.comm_ba = cfg->comm_ba; pc.comm_ransac_a = cfg->comm_ransac_a; pc.comm_ransac_c = cfg->comm_ransac_c; pc.comm_ransac_e = cfg->comm_ransac_e;
+    pc.comm_ba = cfg->comm_ba; pc.comm_ransac = cfg->comm_ransac;
     PipelineResult res;
     if (std::getenv("SFMX_TRACE_PHASES")) std::fprintf(stderr, "phase %-22s %8.3f ms (since entry)\n", "inputs wrapped", since(t_wall) * 1e3);
     run_pipeline(ctx, src, meta, K, pc, res);  // returns after its lanes / prefetch contexts are torn down
@@ -1886,6 +1937,55 @@ int sfmx_host_find_E_ransac(sfmx_ctx* ctx, const double* K9, const double* pi, c
     std::vector<V2> a((size_t)std::max(n, 0)), b((size_t)std::max(n, 0));
     for (int i = 0; i < n; i++) { a[(size_t)i] = {pi[2 * i], pi[2 * i + 1]}; b[(size_t)i] = {pj[2 * i], pj[2 * i + 1]}; }
     const auto r = find_E_ransac_gpu(ctx, K, a, b, iters, thr, min_inliers, nullptr);
+    *n_inl = 0;
+    if (!r) return 0;
+    std::memcpy(R9, r->R_ji.a, 72);
+    t3[0] = r->t_ji.x; t3[1] = r->t_ji.y; t3[2] = r->t_ji.z;
+    *n_inl = (int)r->inliers.size();
+    for (size_t i = 0; i < r->inliers.size(); i++) inliers[i] = r->inliers[i];
+    if (best_iter) *best_iter = r->best_iter;
+    return 1;
+  } catch (const SfmxFailure& e) {
+    return -e.status;
+  } catch (const std::exception&) {
+    return -SFMX_ERR_INVALID;
+  }
+}
+
+// The same seam as `world` ranks would run it (TEST HOOK, one GPU): every virtual rank's half (ransac_local on its iteration
+// range), the merge the two all-reduce(max) compute -- largest packed (count, ~iteration) key, that rank's E as raw bits --
+// and the result as rank `as_rank` forms it: its own mask if it holds the winner, otherwise the mask recomputed from the E bits.
+int sfmx_host_find_E_ransac_world(sfmx_ctx* ctx, const double* K9, const double* pi, const double* pj, int n, int iters, double thr,
+                                  int min_inliers, int world, int as_rank, double* R9, double* t3, int* inliers, int* n_inl, int* best_iter) {
+  using namespace sfmx_host;
+  try {
+    if (world < 1 || as_rank < 0 || as_rank >= world) return -SFMX_ERR_INVALID;
+    Mat3 K;
+    std::memcpy(K.a, K9, 72);
+    std::vector<V2> a((size_t)std::max(n, 0)), b((size_t)std::max(n, 0));
+    for (int i = 0; i < n; i++) { a[(size_t)i] = {pi[2 * i], pi[2 * i + 1]}; b[(size_t)i] = {pj[2 * i], pj[2 * i + 1]}; }
+    std::vector<RansacLocal> loc;
+    std::uint64_t best_key = 0;
+    int best_rank = -1;
+    for (int r = 0; r < world; r++) {
+      loc.push_back(ransac_local(ctx, K, a, b, iters, thr, min_inliers, nullptr, r, world));
+      const RansacLocal& l = loc.back();
+      const std::uint64_t key = l.win_iter >= 0 ? (((std::uint64_t)(std::uint32_t)l.win_count << 32) | (std::uint64_t)(0x7fffffff - l.win_iter)) : 0;
+      if (key > best_key) { best_key = key; best_rank = r; }
+    }
+    RansacLocal mine = std::move(loc[(size_t)as_rank]);
+    if (best_rank < 0) { mine.win_iter = -1; mine.win_count = -1; }
+    else if (best_rank != as_rank) {
+      const RansacLocal& w = loc[(size_t)best_rank];
+      mine.win_iter = w.win_iter;
+      mine.win_count = w.win_count;
+      mine.winE = w.winE;  // travels as raw bits
+      mine.win_mask.assign((size_t)mine.n, 0);
+      std::int32_t cnt = 0;
+      if (mine.n > 0 && sfmx_sampson_mask(ctx, mine.xi.data(), mine.xj.data(), mine.n, mine.winE.a, mine.thr, mine.win_mask.data(), &cnt) != SFMX_OK)
+        return -SFMX_ERR_HIP;
+    }
+    const auto r = ransac_merge(ctx, nullptr, std::move(mine), nullptr);
     *n_inl = 0;
     if (!r) return 0;
     std::memcpy(R9, r->R_ji.a, 72);

@@ -267,6 +267,25 @@ struct RelPose {
   int best_iter = -1;
 };
 
+// One rank's half of a find_E_ransac call (T:646-761): the exact winner of ITS contiguous range of the common iteration
+// stream (ransac_local).  ransac_merge turns the ranks' local winners into the call's result; with one rank it only
+// adds the decomposition (T:680-760).
+struct RansacLocal {
+  bool none = false;               // fewer than 8 correspondences (T:648) or no iterations: the call returns nullopt
+  int n = 0, min_inliers = 0;
+  double thr = 0.0;
+  std::vector<double> xi, xj;      // K^-1-normalised correspondences [n][2]
+  int win_iter = -1, win_count = -1;
+  Mat3 winE;
+  std::vector<std::uint8_t> win_mask;
+};
+// A RANSAC call that ran ahead of the geometry thread: finished (rel) or, in a multi-GPU run, waiting for its merge
+struct RansacAhead {
+  bool merged = true;
+  std::optional<RelPose> rel;
+  RansacLocal local;
+};
+
 // What the geometry lane needs of one frame.  pyr stays valid until FrameFeeder::release_upto(fi).
 struct FramePacket {
   int fi = -1;
@@ -277,7 +296,7 @@ struct FramePacket {
   std::shared_ptr<const CornerMemo> corners;     // accepted-corner sequence, if this frame's image was detected
   // frame->frame find_E_ransac of this step (T:1739), when it was started ahead of the geometry lane (lane A): a pure
   // function of step.prev_pts / cur_pts (RNG seeded inside, T:657).  get() rethrows what it threw ("Singular K").
-  std::shared_future<std::optional<RelPose>> rel;
+  std::shared_future<std::shared_ptr<RansacAhead>> rel;
 };
 
 // Tracker lane.  KLTTracker::step depends on the images and on its own previous state only -- never on poses, keyframe
@@ -328,6 +347,9 @@ void klt_pairs(sfmx_ctx* ctx, const LKConfig& cfg, const sfmx_pyramid* a, const 
 // find_E_ransac (T:646-761); throws std::runtime_error("Singular K") like the reference
 // comm (optional): the iterations are sharded over its ranks; counts are exact per iteration, so every rank returns the
 // single-GPU result bit for bit (all-reduce(max) of the packed (count, iteration) key, winner's E carried as raw bits)
+RansacLocal ransac_local(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters, double thr,
+                         int min_inliers, StageClock* clk, int rank, int world);
+std::optional<RelPose> ransac_merge(sfmx_ctx* ctx, sfmx_comm* comm, RansacLocal&& local, StageClock* clk);
 std::optional<RelPose> find_E_ransac_gpu(sfmx_ctx* ctx, const Mat3& K, const std::vector<V2>& pi, const std::vector<V2>& pj, int iters,
                                          double thr, int min_inliers, StageClock* clk, sfmx_comm* comm = nullptr);
 
@@ -445,13 +467,15 @@ struct PipelineConfig {
   int kf_min_gap = 1, kf_min_inliers = 200;
   double kf_parallax_px = 18.0;
   // Multi-GPU mode (one process per GPU, every rank runs the same sequence): BA points and RANSAC hypotheses are
-  // sharded over the ranks of these communicators.  One communicator per lane that issues collectives:
-  // BA (lane B), frame->frame RANSAC (lane A), loop-closure RANSAC (lane C) and keyframe->keyframe RANSAC (lane E; without
-  // comm_ransac_e a sharded run keeps those on lane C).  null = unsharded.
+  // sharded over the ranks of these communicators.  TWO communicators, each used by exactly one thread at a
+  // time and in an order that is the same on every rank:
+  //   comm_ba      the S | b all-reduce of every BA iteration; issued by lane B, job after job in keyframe order (and by the
+  //                geometry thread for the second BA of an accepted loop closure, while lane B is idle);
+  //   comm_ransac  the winner merge of every find_E_ransac call; issued by the GEOMETRY thread where it consumes the call
+  //                (program order), whichever lane scored the rank's share of the hypotheses ahead of time.
+  // null = unsharded.
   sfmx_comm* comm_ba = nullptr;
-  sfmx_comm* comm_ransac_a = nullptr;
-  sfmx_comm* comm_ransac_c = nullptr;
-  sfmx_comm* comm_ransac_e = nullptr;
+  sfmx_comm* comm_ransac = nullptr;
 };
 struct FrameMeta {
   std::string name;

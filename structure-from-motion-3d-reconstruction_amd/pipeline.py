@@ -19,7 +19,7 @@ class PipelineCfg(ctypes.Structure):
                 ("klt_iters", c_int), ("fb_thresh", c_double), ("kf_min_gap", c_int), ("kf_min_inliers", c_int),
                 ("kf_parallax_px", c_double), ("ba_window", c_int), ("ba_iters", c_int), ("ba_max_points", c_int),
                 ("ba_huber", c_double), ("ba_lambda", c_double),
-                ("comm_ba", c_void_p), ("comm_ransac_a", c_void_p), ("comm_ransac_c", c_void_p), ("comm_ransac_e", c_void_p)]
+                ("comm_ba", c_void_p), ("comm_ransac", c_void_p)]
 
 
 class PipelineStats(ctypes.Structure):
@@ -72,8 +72,9 @@ def load_host_library() -> ctypes.CDLL:
 def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=None, cfg: dict | None = None,
         out_dir: str | None = None, images_dev: int | None = None, shape=None, timing: bool = False, comms=None):
     """Run the per-frame loop.  images: host [F,h,w] u8, or images_dev: device pointer with shape=(F,h,w).
-    comms (optional): (ba, ransac_a, ransac_c[, ransac_e]) capi.Comm objects -- every rank runs the same sequence, BA points
-    and RANSAC hypotheses are sharded over the ranks (without the fourth one the keyframe->keyframe RANSAC stays on lane C)."""
+    comms (optional): (ba, ransac) capi.Comm objects -- every rank runs the same sequence, BA points and RANSAC hypotheses
+    are sharded over the ranks: `ba` carries the S | b all-reduce of lane B, `ransac` the winner merges the geometry
+    thread issues in program order (csrc/host/pipeline.hpp: PipelineConfig)."""
     lib = load_host_library()
     if images is not None:
         images = np.ascontiguousarray(images, np.uint8)
@@ -82,8 +83,9 @@ def run(ctx: capi.Context, images: np.ndarray | None, names, K, lat=None, lon=No
         F, h, w = shape
     c = PipelineCfg(**{**DEFAULTS, **(cfg or {})})
     if comms is not None:
-        hs = [m.h_ if m is not None else None for m in comms] + [None]
-        c.comm_ba, c.comm_ransac_a, c.comm_ransac_c, c.comm_ransac_e = hs[:4]
+        if len(comms) != 2:
+            raise ValueError("comms = (ba, ransac)")
+        c.comm_ba, c.comm_ransac = [m.h_ if m is not None else None for m in comms]
     arr = (c_char_p * F)(*[str(n).encode() for n in names])
     K = np.ascontiguousarray(K, np.float64).reshape(9)
     lat = np.zeros(F) if lat is None else np.ascontiguousarray(lat, np.float64)
@@ -121,6 +123,26 @@ def find_E_ransac(ctx: capi.Context, K, pi, pj, iters: int, thr: float, min_inli
                                      inl.ctypes.data_as(POINTER(c_int)), byref(n_inl), byref(best))
     if rc < 0:
         raise capi.SfmxError(-rc, "find_E_ransac")
+    return dict(ok=rc, R=R, t=t, inliers=inl[:n_inl.value].copy(), best_iter=best.value)
+
+
+def find_E_ransac_world(ctx: capi.Context, K, pi, pj, iters: int, thr: float, min_inliers: int, world: int, as_rank: int):
+    """find_E_ransac as `world` ranks run it, emulated on one GPU (test hook): each virtual rank's local winner, the merge the
+    all-reduces compute, and the result as rank `as_rank` forms it."""
+    lib = load_host_library()
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    pi = np.ascontiguousarray(pi, np.float64)
+    pj = np.ascontiguousarray(pj, np.float64)
+    n = pi.shape[0]
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    inl = np.zeros(max(n, 1), np.int32)
+    n_inl, best = c_int(0), c_int(-1)
+    dp = POINTER(c_double)
+    rc = lib.sfmx_host_find_E_ransac_world(ctx.h_, K.ctypes.data_as(dp), pi.ctypes.data_as(dp), pj.ctypes.data_as(dp), c_int(n), c_int(iters),
+                                           c_double(thr), c_int(min_inliers), c_int(world), c_int(as_rank), R.ctypes.data_as(dp),
+                                           t.ctypes.data_as(dp), inl.ctypes.data_as(POINTER(c_int)), byref(n_inl), byref(best))
+    if rc < 0:
+        raise capi.SfmxError(-rc, "find_E_ransac_world")
     return dict(ok=rc, R=R, t=t, inliers=inl[:n_inl.value].copy(), best_iter=best.value)
 
 

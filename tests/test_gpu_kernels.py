@@ -294,6 +294,33 @@ def test_ransac_degenerate_octets(ctx, kind):
     H.assert_bits_equal(got["t"], g[f"{kind}_t"], "t")
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_find_E_ransac_as_n_ranks_is_the_single_gpu_result(ctx, golden, world):
+    """Hypothesis sharding is exact: each virtual rank's winner of its own iteration range (ransac_local), merged the way the
+    two all-reduce(max) merge them (packed (count, ~iteration) key, winner's E as raw bits), must give every rank -- the one
+    that holds the winner and one that recomputes the mask from the E bits -- the reference's inliers, R and t.  Includes the
+    fixtures where a repeated-index octet wins or ties (ties across ranks resolve to the lowest iteration, T:673)."""
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    for iters, thr, mi in golden["rs_cases"]:
+        tag = f"{int(iters)}_{int(mi)}"
+        for as_rank in (0, world - 1):
+            got = pipe.find_E_ransac_world(ctx, golden["tv_K"], golden["tv_pi"], golden["tv_pj"], int(iters), float(thr), int(mi), world, as_rank)
+            assert got["ok"] == int(golden[f"rs_ok_{tag}"][0]), (tag, as_rank)
+            if got["ok"]:
+                assert np.array_equal(got["inliers"], golden[f"rs_inl_{tag}"]), (tag, as_rank)
+                H.assert_bits_equal(got["R"], golden[f"rs_R_{tag}"], f"R {tag} rank {as_rank}")
+                H.assert_bits_equal(got["t"], golden[f"rs_t_{tag}"], f"t {tag} rank {as_rank}")
+    g = np.load(os.path.join(H.GOLDEN, "ransac_degenerate.npz"))
+    for kind in ("deg_wins", "deg_ties", "clean_wins"):
+        iters, thr, mi = g[f"{kind}_args"]
+        for as_rank in range(world):
+            got = pipe.find_E_ransac_world(ctx, g[f"{kind}_K"], g[f"{kind}_pi"], g[f"{kind}_pj"], int(iters), float(thr), int(mi), world, as_rank)
+            assert got["ok"] == 1 and got["best_iter"] == int(g[f"{kind}_best"][0]), (kind, as_rank)
+            assert np.array_equal(got["inliers"], g[f"{kind}_inl"])
+            H.assert_bits_equal(got["R"], g[f"{kind}_R"], "R")
+            H.assert_bits_equal(got["t"], g[f"{kind}_t"], "t")
+
+
 @pytest.mark.parametrize("case", [(2, 30), (6, 80), (10, 120)])
 def test_ba_build_and_step(ctx, golden, case):
     W, P = case
@@ -624,6 +651,37 @@ def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
     H.assert_bits_equal(dx1, dx2, "sharded (no comm) vs fused dx")
     H.assert_bits_equal(dx1, dx3, "sharded (world 1) vs fused dx")
     comm1.close()
+    prob.close()
+
+
+@pytest.mark.parametrize("shape", [(6, 600, 2), (6, 600, 8), (10, 20000, 8), (3, 7, 8)])
+def test_ba_step_virtual_world(ctx, shape, monkeypatch):
+    """SFMX_VIRTUAL_WORLD=N (test mode of the sharded BA steps): what N ranks compute, formed on one GPU.
+    sfmx_ba_step_sharded_elements (disjoint slices of S | b, +0.0 elsewhere, summed in any order): dx bit for bit.
+    sfmx_ba_step_sharded (shard sums over sfmx_shard_range's point ranges): `relay` (each shard continues the running sums of
+    the one before) IS the reference's sequence, bit for bit; the all-reduce associations (rank order, reverse, ring,
+    pairwise tree) regroup the addends: dx within 1e-9 per step."""
+    W, P, world = shape
+    pw, K, X, ptr, li, uv = _c4_like_problem(W, P, 11)
+    prob = ctx.ba_problem(W, X, ptr, li, uv)
+    a = (pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    monkeypatch.delenv("SFMX_VIRTUAL_WORLD", raising=False)
+    rc, dx_ref = prob.step(*a)
+    assert rc == 0
+    monkeypatch.setenv("SFMX_VIRTUAL_WORLD", str(world))
+    for order in ("rank", "reverse", "ring", "tree"):  # element slices: zeros are all an all-reduce ever adds, whatever its order
+        monkeypatch.setenv("SFMX_VIRTUAL_WORLD_ORDER", order)
+        rc, dx = prob.step_sharded_elements(None, *a)
+        assert rc == 0, order
+        H.assert_bits_equal(dx, dx_ref, f"element-sharded, virtual world {world} {order}")
+    for order in ("relay", "rank", "reverse", "ring", "tree"):
+        monkeypatch.setenv("SFMX_VIRTUAL_WORLD_ORDER", order)
+        rc, dx = prob.step_sharded(None, *a)
+        assert rc == 0, order
+        if order == "relay" or P < world:  # fewer points than ranks: no sharding at all
+            H.assert_bits_equal(dx, dx_ref, f"virtual world {world} {order}")
+        else:
+            assert np.allclose(dx, dx_ref, rtol=0, atol=1e-9 * np.abs(dx_ref).max()), (order, np.abs(dx - dx_ref).max())
     prob.close()
 
 

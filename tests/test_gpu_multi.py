@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_dir):
         D = importlib.import_module(H.PKG_NAME + ".dist")
         from test_gpu_kernels import _c4_like_problem
         ctx = capi.Context(rank)
-        comm_ba, comm_a, comm_c, comm_e = D.make_comms(4, rank)
+        comm_ba, comm_r = D.make_comms(2, rank)
         # ---- point-sharded BA iteration at a C4-like size: every rank gets the same dx, within 1e-9 of one GPU
         W, P = 10, 20000
         pw, K, X, ptr, li, uv = _c4_like_problem(W, P, 5)
@@ -64,7 +64,7 @@ def _worker(rank, world, port, out_dir):
         cfg = H.pipe_cfg_from_json(json.loads(str(g["config"])))
         names = [str(s) for s in g["names"]]
         out = os.path.join(out_dir, f"sharded{rank}")
-        r = pipe.run(ctx, g["images"], names, g["K"], g["lat"], g["lon"], cfg, out, comms=(comm_ba, comm_a, comm_c, comm_e))
+        r = pipe.run(ctx, g["images"], names, g["K"], g["lat"], g["lon"], cfg, out, comms=(comm_ba, comm_r))
         single = os.path.join(out_dir, f"single{rank}")
         r1 = pipe.run(ctx, g["images"], names, g["K"], g["lat"], g["lon"], cfg, single)
         assert r["log"].replace(out, "X") == r1["log"].replace(single, "X")
@@ -75,7 +75,7 @@ def _worker(rank, world, port, out_dir):
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)
         assert all(torch.equal(e.view(torch.int64), every[0].view(torch.int64)) for e in every), "keyframe centres differ between ranks"
-        for m in (comm_ba, comm_a, comm_c, comm_e):
+        for m in (comm_ba, comm_r):
             m.close()
         ctx.close()
         with open(os.path.join(out_dir, f"ok{rank}"), "w") as f:
@@ -102,9 +102,9 @@ def test_pipeline_with_world_size_one_communicators_is_the_plain_pipeline(tmp_pa
     names = [str(s) for s in g["names"]]
     a = str(tmp_path / "a")
     r1 = pipe.run(ctx, g["images"], names, g["K"], g["lat"], g["lon"], cfg, a)
-    for n_comms in (4, 3):  # 3: no communicator for lane E -> the keyframe->keyframe RANSAC stays on lane C
-        comms = tuple(capi.Comm(0, None, 0, 1) for _ in range(n_comms))
-        b = str(tmp_path / f"b{n_comms}")
+    for k in range(2):
+        comms = tuple(capi.Comm(0, None, 0, 1) for _ in range(2))
+        b = str(tmp_path / f"b{k}")
         r2 = pipe.run(ctx, g["images"], names, g["K"], g["lat"], g["lon"], cfg, b, comms=comms)
         assert r1["log"].replace(a, "X") == r2["log"].replace(b, "X")
         for fn in ("keyframes_camera_centers.csv", "posegraph_edges.csv", "templeRing_sparse_points.ply"):

@@ -127,6 +127,37 @@ def test_pipeline_c3_5000_tracks_vs_oracle(ctx, tmp_path):
     _same_files(out_g, out_o)
 
 
+def test_c5_end_to_end_1080p_loop_closure_posegraph(ctx, tmp_path, monkeypatch):
+    """BASELINE config C5 in ONE run of the per-frame loop (T:1708-1871): 1920x1080 frames on an out-and-back ring path, so
+    that the descriptor search finds old keyframes again, the LK + RANSAC verification accepts them (T:1822-1858) and every
+    accepted loop closure runs the pose graph and the second BA (T:1859-1863).  With the pose graph on the reference's own
+    dense system (SFMX_POSEGRAPH_SOLVER=dense) stdout and all three files are byte-equal to the oracle's; with the
+    structured FP64-MFMA solver (the product path above 6 400 unknowns, forced here) the same keyframes / edges come out
+    and the centres agree to 1e-9 of their magnitude."""
+    ang = [0.1 * a for a in (0, 1, 2, 3, 4, 5, 6, 5, 4, 3, 2, 1, 0, 1)]
+    seq = synth.make_sequence(len(ang), 1920, 1080, 0.1, n_blobs=20000, seed=13, angles=ang)
+    cfg = dict(H.PIPE_DEFAULTS, frames=len(ang), kf_min_inliers=100, kf_parallax_px=1.0)
+    out_o = str(tmp_path / "orc")
+    rc, olog, nk, npnt = H.orc_pipeline_run(seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out_o)
+    edges_o = open(os.path.join(out_o, "posegraph_edges.csv")).read().splitlines()
+    n_loops = sum(1 for l in edges_o[1:] if l.endswith(",1"))
+    assert rc == 0 and nk == len(ang) and n_loops >= 3, (rc, nk, n_loops)
+    monkeypatch.setenv("SFMX_POSEGRAPH_SOLVER", "dense")
+    out_d = str(tmp_path / "dense")
+    rd = pipe.run(ctx, seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out_d)
+    assert rd["log"].replace(out_d, "X") == olog.replace(out_o, "X")
+    _same_files(out_d, out_o)
+    assert rd["stats"]["n_keyframes"] == nk and rd["stats"]["n_points"] == npnt and rd["stats"]["ransac_cert_misses"] == 0
+    monkeypatch.setenv("SFMX_POSEGRAPH_SOLVER", "structured")
+    out_s = str(tmp_path / "structured")
+    rs = pipe.run(ctx, seq["images"], seq["names"], seq["K"], seq["lat"], seq["lon"], cfg, out_s)
+    assert rs["log"].replace(out_s, "X") == olog.replace(out_o, "X")
+    assert open(os.path.join(out_s, "posegraph_edges.csv")).read() == open(os.path.join(out_o, "posegraph_edges.csv")).read()
+    cd, cs = rd["centres"], rs["centres"]
+    assert cd.shape == cs.shape == (nk, 3)
+    assert np.allclose(cs, cd, rtol=0, atol=1e-9 * np.abs(cd).max()), np.abs(cs - cd).max() / np.abs(cd).max()
+
+
 def test_device_resident_frames_give_identical_results(ctx, tmp_path):
     import torch
     g = np.load(os.path.join(H.GOLDEN, "e2e_keyframes.npz"))
