@@ -78,11 +78,16 @@ def cpu_baseline(seq, cfg, sample_frames: int):
                 frames_per_s=sample_frames / dt)
 
 
-def run_ba_sharded(capi, synth, rank, local_rank, world, steps, warmup, ctx=None, comm=None):
-    """BASELINE config C4: local BA on W=10 poses, P=50 000 points, every point seen by every pose (500 k residuals), points
-    sharded over the ranks; a step = one BA iteration = partial build of S|b on this rank's points, RCCL all-reduce(sum) of
-    D*D + D = 3 660 doubles in HBM, damping + gauge, dense solve on the device, dx to the host.  torch.distributed must be
-    up when world > 1 (it carries the unique id and the max-time reduction).  Returns the result dict (meaningful on rank 0)."""
+def run_ba_sharded(capi, synth, rank, local_rank, world, steps, warmup, ctx=None, comm=None, shard="elements"):
+    """BASELINE config C4: local BA on W=10 poses, P=50 000 points, every point seen by every pose (500 k residuals), sharded
+    over the ranks; a step = one BA iteration = build of this rank's share of S|b, RCCL all-reduce(sum) of D*D + D = 3 660
+    doubles in HBM, damping + gauge, dense solve on the device, dx to the host.
+    shard = "elements" (sfmx_ba_step_sharded_elements, the parity mode): every rank holds all points, computes the per-point
+    records (replicated) and reduces a disjoint slice of the elements of S|b, the all-reduce adds zeros -- bit-identical to one GPU;
+    shard = "points" (sfmx_ba_step_sharded, tolerance mode): every rank holds a contiguous range of the points, the all-reduce
+    regroups the addends of every element.
+    torch.distributed must be up when world > 1 (it carries the unique id and the max-time reduction).  Returns the result
+    dict (meaningful on rank 0)."""
     import torch
     import torch.distributed as dist
     D = importlib.import_module(PKG + ".dist")
@@ -104,10 +109,11 @@ def run_ba_sharded(capi, synth, rank, local_rank, world, steps, warmup, ctx=None
         ctx = capi.Context(local_rank)
     if own_comm:
         comm = D.make_comms(1, local_rank)[0]
-    lo, hi = capi.shard_range(P, rank, world)
+    lo, hi = capi.shard_range(P, rank, world) if shard == "points" else (0, P)
     o0, o1 = int(ptr[lo]), int(ptr[hi])
     prob = ctx.ba_problem(W, X[lo:hi], ptr[lo:hi + 1] - o0, li[o0:o1], uv[o0:o1])
     a = (pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    step = prob.step_sharded if shard == "points" else prob.step_sharded_elements
 
     def barrier():
         if world > 1:
@@ -115,11 +121,11 @@ def run_ba_sharded(capi, synth, rank, local_rank, world, steps, warmup, ctx=None
         torch.cuda.synchronize()
 
     for _ in range(max(1, warmup)):
-        rc, dx = prob.step_sharded(comm, *a)
+        rc, dx = step(comm, *a)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        rc, dx = prob.step_sharded(comm, *a)
+        rc, dx = step(comm, *a)
     ctx.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -129,24 +135,24 @@ def run_ba_sharded(capi, synth, rank, local_rank, world, steps, warmup, ctx=None
         dt = float(t.item())
     ctx.set_timing(True)
     for _ in range(3):
-        prob.step_sharded(comm, *a)
+        step(comm, *a)
     prof = {k: v for k, v in ctx.kernel_profile().items() if v[1] > 0}
     ctx.set_timing(False)
-    Pl, R = hi - lo, (hi - lo) * W
-    # SURVEY.md 8(d) for THIS rank's shard, per BA iteration: 535 flop per residual + (126 n + 180 n^2 + 40) per point (n = W poses
+    Pl, R = (hi - lo, (hi - lo) * W) if shard == "points" else ((P + world - 1) // world, (P * W + world - 1) // world)
+    # SURVEY.md 8(d) for THIS rank's share (points: its point range; elements: 1 / world of the system), per BA iteration: 535 flop per residual + (126 n + 180 n^2 + 40) per point (n = W poses
     # see the point); bytes 20 R + 24 P + 96 W read, 8 (D^2 + D) written -- the figures the roofline is priced on.  What the
     # kernels move on top of that (the contribution rows) shows up in `kernel_us_per_step`, not in `achieved`.
     Dd = 6 * W
     alg_flop = 535.0 * R + Pl * (126.0 * W + 180.0 * W * W + 40.0)
     alg_bytes = 20.0 * R + 24.0 * Pl + 96.0 * W + 8.0 * (Dd * Dd + Dd)
     step_s = dt / steps
-    out = {"metric": "BA iterations/sec, BASELINE config C4 (W=10 poses, P=50 000 points, 500 k residuals), points sharded over the ranks",
+    out = {"metric": f"BA iterations/sec, BASELINE config C4 (W=10 poses, P=50 000 points, 500 k residuals), {shard} of the system sharded over the ranks",
            "value": round(steps / dt, 3), "unit": "iterations/s", "n_gpus": world, "rccl_world": world, "steps": steps, "warmup": warmup,
-           "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "strong", "mode": "ba-sharded",
-           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "strong", "mode": "ba-sharded", "shard": shard,
+           "bit_identical_to_one_gpu": shard == "elements" or world == 1, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "local BA S|b build + reduce + dense solve, W=10, P=50000, every point in every pose, N(0,0.5 px) noise",
-                      "points_per_rank": Pl, "allreduce_doubles": Dd * Dd + Dd, "allreduce_bytes_per_step": 8 * (Dd * Dd + Dd),
-                      "parallelism": f"BA points x{world}, RCCL all-reduce(sum) of S|b in HBM"},
+                      "points_per_rank": hi - lo, "allreduce_doubles": Dd * Dd + Dd, "allreduce_bytes_per_step": 8 * (Dd * Dd + Dd),
+                      "parallelism": f"BA {shard} x{world}, RCCL all-reduce(sum) of S|b in HBM"},
            "roofline": {"bound": "valu_fp64", "achieved": round(alg_flop / step_s / 1e12, 4), "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(alg_flop / step_s / 1e12 / FP64_VALU_PEAK_TF, 5), "traffic": None,
                         "algorithmic_flop_per_step": int(alg_flop), "algorithmic_bytes_per_step": int(alg_bytes),
@@ -169,7 +175,7 @@ def bench_ba_sharded(args, capi, synth, rank, local_rank, world):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    out = run_ba_sharded(capi, synth, rank, local_rank, world, args.steps, args.warmup)
+    out = run_ba_sharded(capi, synth, rank, local_rank, world, args.steps, args.warmup, shard=args.ba_shard)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -195,6 +201,8 @@ def main():
     ap.add_argument("--sharded-probe", type=int, default=1,
                     help="default mode: after the headline also time the sharded BA step (C4) and one sequence on all ranks and "
                          "report them as `sharded_ba` / `sharded_sequence` (0 = skip)")
+    ap.add_argument("--ba-shard", choices=("elements", "points"), default="elements",
+                    help="--mode ba-sharded: elements (parity mode, sfmx_ba_step_sharded_elements) or points (tolerance mode)")
     ap.add_argument("--sharded-timeout", type=float, default=240.0, help="watchdog of the sharded sub-benchmarks, seconds")
     ap.add_argument("--mode", choices=("sequences", "ba-sharded", "sharded-sequence"), default="sequences",
                     help="sequences (headline): one independent sequence per rank, weak scaling, no data-path collective; "
@@ -331,7 +339,10 @@ def main():
             Dm = importlib.import_module(PKG + ".dist")
             # C4 through sfmx_ba_step_sharded
             try:
-                sharded["sharded_ba"] = run_ba_sharded(capi, synth, rank, local_rank, world, 10, 2)
+                sharded["sharded_ba"] = run_ba_sharded(capi, synth, rank, local_rank, world, 10, 2, shard="elements")
+                if world > 1:  # the tolerance mode next to it (with one rank both are the plain step)
+                    pts = run_ba_sharded(capi, synth, rank, local_rank, world, 10, 2, shard="points")
+                    sharded["sharded_ba"]["tolerance_mode_points"] = {k: pts[k] for k in ("value", "unit", "ms_per_step", "shard", "bit_identical_to_one_gpu")}
             except Exception as e:
                 sharded["sharded_ba"] = {"error": repr(e), "rccl_world": world}
             # one sequence on all ranks: every rank holds rank 0's sequence

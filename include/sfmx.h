@@ -125,8 +125,10 @@ int sfmx_klt_track(sfmx_ctx* ctx, const sfmx_pyramid* pyr_a, const sfmx_pyramid*
  * are derived on the host with libm instead (the reference's E bit for bit, flags bit 0) and
  * scored with that.
  *
- * counts_out [H]: #{err < thr}.  lo_out/hi_out [H] (optional): certified bounds of the
- * REFERENCE's count of that iteration: a point counts for lo only if it stays an inlier, for hi
+ * counts_out [H]: #{err < thr}.  lo_out/hi_out [H] (optional): bounds of the REFERENCE's count of
+ * that iteration under the EMPIRICAL contract above (|E_dev - E_ref| <= 1e-16 / cond: measured, not
+ * derived; a caller that needs the reference's winner verifies candidates exactly, as
+ * ransac_local in csrc/host/pipeline.cpp does, and falls back to exact counts if a bound fails): a point counts for lo only if it stays an inlier, for hi
  * if it can become one, when every entry of E moves by 1e-16 / cond (per-point bound, see
  * k_score); lo == hi == count for the exact hypotheses.  flags_out [H] (optional): bit 0 = exact
  * host hypothesis.  cond_out [H] (optional): the conditioning estimate (+inf for exact ones).

@@ -46,6 +46,8 @@ struct sfmx_ba_problem {
   double* work = nullptr;     // solve scratch: dx [D] + status
   double* contrib = nullptr;  // [P][CS] per-point contribution rows
   unsigned* ticket = nullptr;  // finished-workgroup counter of the fused reduce + solve (zero between launches)
+  hipEvent_t ev_sync = nullptr, ev_exp[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};  // chunked expand / reduce pipeline
+  int chunk = 0;                // points per chunk of the contribution-row ring (0: all rows resident)
 };
 
 // dense.hpp:96-119
@@ -386,16 +388,17 @@ __global__ __launch_bounds__(64) void k_ba_points_bulk(BA_POINTS_PARAMS) { ba_po
 // the rank that reduces those elements reads nothing else (entry k < D*D feeds S element k; an Hxx entry feeds the diagonal-block
 // element at the same (row, column); bx and G*bp entries feed b).
 __global__ __launch_bounds__(256) void k_ba_expand(int W, int P, int MS, const double* __restrict__ rec, const int8_t* __restrict__ slot_of,
-                                                   double* __restrict__ C, int e_lo, int e_hi) {
+                                                   double* __restrict__ C, int e_lo, int e_hi, int p_base) {
+  // p_base: the launch covers points p_base .. p_base + gridDim.x - 1 and writes their rows to C[0 ..] (a chunk of the row ring)
   __shared__ double srec[BA_MAX_OBS * BA_SLOT];
   __shared__ int8_t sso[BA_MAX_W];
   const int D = 6 * W, CS = ba_row_stride(W);
-  const int p = blockIdx.x, tid = threadIdx.x;
+  const int p = (int)blockIdx.x + p_base, tid = threadIdx.x;
   const double* base = rec + (size_t)p * MS * BA_SLOT;
   for (int k = tid; k < MS * BA_SLOT; k += 256) srec[k] = base[k];
   if (tid < W) sso[tid] = slot_of[(size_t)p * W + tid];
   __syncthreads();
-  double* row = C + (size_t)p * CS;
+  double* row = C + (size_t)blockIdx.x * CS;
   const bool all = e_lo <= 0 && e_hi >= D * D + D;
   for (int e = tid; e < CS; e += 256) {
     double v = 0.0;
@@ -761,7 +764,8 @@ template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
 __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
                                                    double* __restrict__ S, double* __restrict__ b,
                                                    unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
-                                                   unsigned long long seq, int wave_prio, const double* init = nullptr, int wg_off = 0) {
+                                                   unsigned long long seq, int wave_prio, const double* init = nullptr, int wg_off = 0,
+                                                   int publish_system = 0) {
   // init (optional, [D*D + D] in S | b layout, may alias S): the chains start from these values instead of +0.0 -- a shard
   // that continues the running sums of the shard before it (relay mode: the reference's sequence across shards)
   if (wave_prio) __builtin_amdgcn_s_setprio(3);  // see k_ba_points
@@ -900,9 +904,21 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
     __syncthreads();
     if (tid == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
     __syncthreads();
-    if (!is_last || tid >= 64) return;
+    if (!is_last) return;
     __threadfence();  // acquire: S | b of every other workgroup
     if (tid == 0) *ticket = 0;  // for the next launch on this stream
+    if (publish_system) {
+      // the host solves (csrc/hip/solve_host.cpp): S | b -- 10 KB at 36 unknowns -- into pinned host memory by this one workgroup,
+      // then the sequence word (system-scope release) the host is polling
+      const int ne = SOLVE_N * SOLVE_N + SOLVE_N;
+      for (int k = tid; k < ne; k += 256) host_out[k] = S[k];  // S | b are contiguous
+      __threadfence_system();
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + ne), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    if (tid >= 64) return;
     double xr = 0.0;
     int st = 0;
     int* dstatus = reinterpret_cast<int*>(work + SOLVE_N);
@@ -1279,45 +1295,91 @@ __global__ void k_ba_publish(const double* __restrict__ work, int D, double* __r
 // fused: 0 = sums only; otherwise the last workgroup of the reduction also solves and publishes (D = 36 / 60 only: see
 // ba_can_fuse_solve), to q->work and, if host_out is given, to pinned host memory with sequence word `seq`
 static bool ba_can_fuse_solve(const sfmx_ba_problem* q) { return q->W == 6 || q->W == 10; }
-// points phase of one iteration (records + contribution rows of every point of the problem)
-static int ba_launch_points(sfmx_ctx* c, sfmx_ba_problem* q, const double* d_poses, double fx, double fy, double cx, double cy, double huber,
-                            int wave_prio, int e_lo = 0, int e_hi = 0x7fffffff) {
+// Shape of a problem: window-sized ones (or SFMX_BA_EXPAND=merged) get their contribution rows from the points kernel itself, all
+// rows resident; large ones (C4: 50 000 points x 32 KB) expand CHUNKS of points into a two-slot ring that stays inside the
+// 256 MB Infinity Cache while the reduction consumes the other slot (ba_launch_reduce).
+static bool ba_merged(const sfmx_ba_problem* q) {
   static const char* expand_env = getenv("SFMX_BA_EXPAND");  // "split" / "merged": A/B and tests
-  const bool merged = expand_env ? expand_env[0] == 'm' : q->P <= BA_MERGED_EXPAND_MAX_P;
-  if (merged) {
+  return expand_env ? expand_env[0] == 'm' : q->P <= BA_MERGED_EXPAND_MAX_P;
+}
+static int ba_chunk_points() {
+  static const int v = getenv("SFMX_BA_CHUNK") ? atoi(getenv("SFMX_BA_CHUNK")) : 4096;
+  return v < 128 ? 128 : v;
+}
+// points phase of one iteration: the records of every point (and, in the merged shape, their contribution rows)
+static int ba_launch_points(sfmx_ctx* c, sfmx_ba_problem* q, const double* d_poses, double fx, double fy, double cx, double cy, double huber,
+                            int wave_prio) {
+  if (ba_merged(q)) {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window<<<(q->P + BA_PTS - 1) / BA_PTS, 256, 0, c->stream>>>(
                                     q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
   } else {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_bulk<<<(q->P + 63) / 64, 64, 0, c->stream>>>(q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx,
                                                                                          fy, cx, cy, huber, q->rec, q->slot_of, nullptr, wave_prio)));
-    SFMX_PROF(c, KID_BA_EXPAND, (k_ba_expand<<<q->P, 256, 0, c->stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, q->contrib, e_lo, e_hi)));
   }
   return SFMX_OK;
 }
-// reduction phase over the contribution rows of points [p_lo, p_lo + p_cnt) into S_out | b_out; init: see k_ba_reduce
-// wg_lo / wg_cnt (element-sharded step): only the element blocks [wg_lo, wg_lo + wg_cnt) of BAR_COLS elements each are reduced
 static int ba_element_blocks(const sfmx_ba_problem* q) { const int D = 6 * q->W; return (D * D + D + BAR_COLS - 1) / BAR_COLS; }
+// one reduction launch over `p_cnt` rows starting at `rows`
+static void ba_reduce_kernel(sfmx_ctx* c, sfmx_ba_problem* q, const double* rows, int p_cnt, double lambda, int damp, double* S_out, double* b_out,
+                             const double* init, bool fused_solve, double* host_out, unsigned long long seq, int wave_prio, int wg_lo, int nwg,
+                             int publish_system, bool streaming) {
+  if (fused_solve && q->W == 6) {
+    k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, q->ticket, q->work, host_out, seq, wave_prio, init,
+                                                         wg_lo, publish_system);
+  } else if (fused_solve && q->W == 10) {
+    k_ba_reduce<128, 60, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, q->ticket, q->work, host_out, seq, wave_prio, init,
+                                                          wg_lo, publish_system);
+  } else if (!streaming) {
+    k_ba_reduce<64, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, nullptr, nullptr, nullptr, 0, wave_prio, init, wg_lo);
+  } else {
+    k_ba_reduce<128, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, nullptr, nullptr, nullptr, 0, wave_prio, init, wg_lo);
+  }
+}
+// Reduction phase over the points [p_lo, p_lo + p_cnt) into S_out | b_out; init: see k_ba_reduce.
+// wg_lo / wg_cnt, e_lo / e_hi (element-sharded step): only the element blocks [wg_lo, wg_lo + wg_cnt) of BAR_COLS elements are
+// reduced, and only the row entries that feed elements [e_lo, e_hi) are expanded.
+// Large problems: the rows of a chunk of points are expanded on the context's second stream into one slot of a two-slot ring
+// while the reduction kernel of the chunk before it runs on the first; every element's chain continues from chunk to chunk in
+// S_out itself (init = S_out), so the sums are the reference's sequence over all points and the 1.6 GB that a C4 iteration used to
+// write and read back never leave the Infinity Cache (2 x 134 MB at W = 10).
 static int ba_launch_reduce(sfmx_ctx* c, sfmx_ba_problem* q, int p_lo, int p_cnt, double lambda, int damp, double* S_out, double* b_out,
                             const double* init, bool fused_solve, double* host_out, unsigned long long seq, int wave_prio, int wg_lo = 0,
-                            int wg_cnt = -1) {
+                            int wg_cnt = -1, int publish_system = 0, int e_lo = 0, int e_hi = 0x7fffffff) {
   const size_t CS = (size_t)36 * q->W * q->W + 48 * q->W;
-  const double* rows = q->contrib + (size_t)p_lo * CS;
   const int nwg = wg_cnt >= 0 ? wg_cnt : ba_element_blocks(q);
-  if (nwg == 0) return SFMX_OK;
+  if (nwg == 0 || p_cnt <= 0) return SFMX_OK;
   if (wg_cnt >= 0) fused_solve = false;  // a slice of the system: nothing to solve yet
-  if (fused_solve && q->W == 6) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
-                                                                              q->ticket, q->work, host_out, seq, wave_prio, init, wg_lo)));
-  } else if (fused_solve && q->W == 10) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 60, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
-                                                                              q->ticket, q->work, host_out, seq, wave_prio, init, wg_lo)));
-  } else if (q->P <= BA_MERGED_EXPAND_MAX_P) {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<64, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
-                                                                                   nullptr, nullptr, nullptr, 0, wave_prio, init, wg_lo)));
-  } else {
-    SFMX_PROF(c, KID_BA_REDUCE, (k_ba_reduce<128, 0, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out,
-                                                                                    nullptr, nullptr, nullptr, 0, wave_prio, init, wg_lo)));
+  if (q->chunk == 0) {  // all rows resident (written by k_ba_points_window)
+    SFMX_PROF(c, KID_BA_REDUCE, ba_reduce_kernel(c, q, q->contrib + (size_t)p_lo * CS, p_cnt, lambda, damp, S_out, b_out, init, fused_solve, host_out, seq,
+                                                 wave_prio, wg_lo, nwg, publish_system, q->P > BA_MERGED_EXPAND_MAX_P));
+    return SFMX_OK;
   }
+  if (!q->ev_sync) {
+    SFMX_HIP(c, hipEventCreateWithFlags(&q->ev_sync, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+      SFMX_HIP(c, hipEventCreateWithFlags(&q->ev_exp[k], hipEventDisableTiming));
+      SFMX_HIP(c, hipEventCreateWithFlags(&q->ev_red[k], hipEventDisableTiming));
+    }
+  }
+  prof_begin(c, KID_BA_REDUCE);  // expansion (second stream) + reduction of all chunks as one profile entry
+  // the second stream starts behind everything queued so far: the points kernel, and earlier reductions that read the ring
+  SFMX_HIP(c, hipEventRecord(q->ev_sync, c->stream));
+  SFMX_HIP(c, hipStreamWaitEvent(c->copy_stream, q->ev_sync, 0));
+  const int chunk = q->chunk, p_end = p_lo + p_cnt;
+  int k = 0;
+  for (int p0 = p_lo; p0 < p_end; p0 += chunk, ++k) {
+    const int cnt = p_end - p0 < chunk ? p_end - p0 : chunk;
+    const bool last = p0 + cnt >= p_end;
+    double* slot = q->contrib + (size_t)(k & 1) * chunk * CS;
+    if (k >= 2) SFMX_HIP(c, hipStreamWaitEvent(c->copy_stream, q->ev_red[k & 1], 0));  // the reduction that read this slot is done
+    k_ba_expand<<<cnt, 256, 0, c->copy_stream>>>(q->W, q->P, q->MS, q->rec, q->slot_of, slot, e_lo, e_hi, p0);
+    SFMX_HIP(c, hipEventRecord(q->ev_exp[k & 1], c->copy_stream));
+    SFMX_HIP(c, hipStreamWaitEvent(c->stream, q->ev_exp[k & 1], 0));
+    ba_reduce_kernel(c, q, slot, cnt, lambda, last ? damp : 0, S_out, b_out, k == 0 ? init : S_out, last && fused_solve, host_out, seq, wave_prio, wg_lo,
+                     nwg, publish_system, true);
+    SFMX_HIP(c, hipEventRecord(q->ev_red[k & 1], c->stream));
+  }
+  prof_end(c);
   return SFMX_OK;
 }
 static const double* ba_stage_poses(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, bool zero_copy_poses, int* rc_out) {
@@ -1337,14 +1399,14 @@ static int ba_wave_prio() {
 }
 static int ba_launch_build(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy,
                            double huber, double lambda, int damp, KernelTimer& t, bool zero_copy_poses = false, bool fused_solve = false,
-                           double* host_out = nullptr, unsigned long long seq = 0) {
+                           double* host_out = nullptr, unsigned long long seq = 0, int publish_system = 0) {
   int rc = SFMX_OK;
   const double* d_poses = ba_stage_poses(c, q, poses_wc, zero_copy_poses, &rc);
   if (rc) return rc;
   t.start();
   rc = ba_launch_points(c, q, d_poses, fx, fy, cx, cy, huber, ba_wave_prio());
   if (rc) return rc;
-  rc = ba_launch_reduce(c, q, 0, q->P, lambda, damp, q->S, q->b, nullptr, fused_solve, host_out, seq, ba_wave_prio());
+  rc = ba_launch_reduce(c, q, 0, q->P, lambda, damp, q->S, q->b, nullptr, fused_solve, host_out, seq, ba_wave_prio(), 0, -1, publish_system);
   if (rc) return rc;
   t.stop();
   SFMX_HIP(c, hipGetLastError());
@@ -1435,9 +1497,11 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
   auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   const size_t o_x = 0, o_uv = up16((size_t)P * 24), o_ptr = o_uv + up16((size_t)R * 16), o_li = o_ptr + up16((size_t)(P + 1) * 4);
   const size_t in_bytes = o_li + up16((size_t)R * 4) + 16;
+  q->chunk = ba_merged(q) ? 0 : ba_chunk_points();
+  const size_t row_slots = q->chunk ? (size_t)2 * q->chunk : (size_t)P;  // all rows, or the two-slot ring of chunks
   const size_t need[11] = {in_bytes, 16, 16, 16, (size_t)W * 96,
                            (size_t)P * q->MS * BA_SLOT * 8, (size_t)P * W, (size_t)D * D * 8 + (size_t)D * 8, 16, (size_t)D * 8 + 64,
-                           (size_t)P * CS * 8};
+                           row_slots * CS * 8};
   const void* ticket_before = q->bufs[8].p;
   for (int i = 0; i < 11; i++) SFMX_HIP(c, q->bufs[i].ensure(need[i]));
   const bool new_ticket = q->bufs[8].p != ticket_before;  // zeroed once: every launch leaves the counter at zero
@@ -1482,8 +1546,13 @@ int sfmx_ba_create(sfmx_ctx* c, int W, int P, const double* X, const int32_t* ob
 
 void sfmx_ba_destroy(sfmx_ctx* c, sfmx_ba_problem* q) {
   if (!q) return;
-  if (c) (void)hipStreamSynchronize(c->stream);
+  if (c) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream); }
   for (auto& b : q->bufs) b.release();
+  if (q->ev_sync) (void)hipEventDestroy(q->ev_sync);
+  for (int k = 0; k < 2; k++) {
+    if (q->ev_exp[k]) (void)hipEventDestroy(q->ev_exp[k]);
+    if (q->ev_red[k]) (void)hipEventDestroy(q->ev_red[k]);
+  }
   delete q;
 }
 
@@ -1516,21 +1585,29 @@ int sfmx_ba_build_partial(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_w
   return SFMX_OK;
 }
 
+// csrc/hip/solve_host.cpp (g++): dense.hpp:54-93 on the host core that polls for the result
+extern "C" int sfmx_host_solve_window(const double* S, const double* b, int n, double* x, double* work);
+
 int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy, double huber,
                  double lambda, double* dx_out) {
   SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
-  const int D = 6 * q->W;
+  const int D = 6 * q->W, NE = D * D + D;
   static const bool no_poll = getenv("SFMX_BA_NO_POLL") != nullptr;
   static const bool no_fuse = getenv("SFMX_BA_NO_FUSE") != nullptr;  // A/B and tests: reduce, solve and publish as separate launches
+  // Where the window's system is solved: on the polling host core by default (3-4 us; the elimination is a chain of dependent
+  // steps that one wavefront needs ~30 us for), SFMX_BA_SOLVE=device keeps it in the last workgroup of the reduction.
+  const char* solve_env = getenv("SFMX_BA_SOLVE");  // read per call: the tests switch it inside one process
+  const bool host_solve_on = !(solve_env && std::string(solve_env) == "device");
   const bool poll = !c->timing && !no_poll;  // the event timers need the stream synchronisation
   const bool fuse = ba_can_fuse_solve(q) && !no_fuse;
+  const bool host_solve = host_solve_on && poll && fuse;
   KernelTimer t(c);
-  SFMX_HIP(c, c->h[1].ensure((size_t)D * 8 + 32));
+  SFMX_HIP(c, c->h[1].ensure(host_solve ? (size_t)NE * 8 + 32 : (size_t)D * 8 + 32));
   double* hout = c->h[1].as<double>();
-  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(hout + D + 1);
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(host_solve ? hout + NE : hout + D + 1);
   const unsigned long long seq = ++c->ba_seq;
   if (poll) *flag = 0;  // (a freshly grown buffer holds arbitrary bytes)
-  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t, poll, fuse, poll ? hout : nullptr, seq);
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t, poll, fuse, poll ? hout : nullptr, seq, host_solve ? 1 : 0);
   if (rc) return rc;
   if (!fuse) {
     int* dstatus = reinterpret_cast<int*>(q->work + D);
@@ -1554,6 +1631,12 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
       }
     }
     c->ba_upload_in_flight = false;  // everything queued before the solve has completed
+    if (host_solve) {
+      double work[60 * 61];
+      static_assert(BA_MAX_W >= 10, "window sizes with a fused reduction: 6 and 10 poses");
+      status = sfmx_host_solve_window(hout, hout + (size_t)D * D, D, dx_out, work);
+      return status ? SFMX_ERR_SINGULAR : SFMX_OK;
+    }
     memcpy(dx_out, hout, (size_t)D * 8);
     memcpy(&status, hout + D, 4);
     return status ? SFMX_ERR_SINGULAR : SFMX_OK;
@@ -1626,9 +1709,11 @@ int sfmx_ba_step_sharded_elements(sfmx_ctx* c, sfmx_comm* comm, sfmx_ba_problem*
     const int e_lo = b_lo * BAR_COLS, e_hi = b_hi * BAR_COLS < NE ? b_hi * BAR_COLS : NE;
     double* S_out = part ? part + (size_t)r * NE : q->S;
     if (!part && world > 1) SFMX_HIP(c, hipMemsetAsync(q->S, 0, (size_t)NE * 8, c->stream));  // S | b contiguous: +0.0 outside the slice
-    rc = ba_launch_points(c, q, d_poses, fx, fy, cx, cy, huber, ba_wave_prio(), e_lo, e_hi);
-    if (rc) return rc;
-    rc = ba_launch_reduce(c, q, 0, q->P, 0.0, 0, S_out, S_out + (size_t)D * D, nullptr, false, nullptr, 0, ba_wave_prio(), b_lo, b_hi - b_lo);
+    if (r == 0) {  // the records do not depend on the slice
+      rc = ba_launch_points(c, q, d_poses, fx, fy, cx, cy, huber, ba_wave_prio());
+      if (rc) return rc;
+    }
+    rc = ba_launch_reduce(c, q, 0, q->P, 0.0, 0, S_out, S_out + (size_t)D * D, nullptr, false, nullptr, 0, ba_wave_prio(), b_lo, b_hi - b_lo, 0, e_lo, e_hi);
     if (rc) return rc;
   }
   if (part) {

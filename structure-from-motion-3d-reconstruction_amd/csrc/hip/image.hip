@@ -400,6 +400,182 @@ __global__ __launch_bounds__(256) void k_shi_round(const double* __restrict__ sc
   }
 }
 
+// ---- tile-resident fixpoint ----------------------------------------------------------------------------
+// The dense sweeps above pay a staging of scores + states per sweep and the list sweeps a full disc scan per undecided pixel
+// per sweep (33 MB of traffic and ~20 launches per VGA image).  k_shi_tile keeps a TW x TH tile and its (min_dist - 1) halo in
+// LDS for a whole PASS and iterates rules (A) / (R) there until nothing inside the tile changes:
+//   * every undecided pixel keeps a WITNESS -- one live pixel of its disc whose score is >= its own, the strongest found.  While
+//     the witness is live the pixel cannot be accepted, so a round costs it two LDS reads; an accepted witness of strictly
+//     greater score rejects it (R).  Only a pixel whose witness has been rejected looks for a new one: its eight neighbours
+//     first (the score field is smooth), the whole disc only if they have none (sixteen lanes per pixel); no witness at all
+//     = every pixel of the disc with a score >= its own is rejected = accepted (A);
+//   * a newly accepted pixel STAMPS its disc: every undecided pixel of strictly smaller score is rejected at once (R from the
+//     accepted side), which is what makes the dependency chains short.
+// Halo pixels keep the state they had when the tile was staged (a decision is a certain fact, an old state only says less:
+// any mix of old and new states is sound) and are owned by the neighbouring tile; what stays undecided along tile borders is
+// taken up by the next pass, whose tile grid is shifted by half a tile.  After the last pass the undecided pixels travel to the
+// host with the accepted ones, exactly as before.  state: 0 below threshold, 1 undecided, 2 accepted, 3 rejected.
+#define SHT_TW 64
+#define SHT_TH 32
+#define SHT_THREADS 512
+#define SHT_NONE 0xffffu
+__global__ __launch_bounds__(SHT_THREADS) void k_shi_tile(const double* __restrict__ score, int w, int h, int md, uint8_t* __restrict__ state,
+                                                          const unsigned long long* __restrict__ max_bits, double quality, int first_pass,
+                                                          int offx, int offy, const int8_t* __restrict__ taps_g, int ntaps, int max_rounds) {
+  extern __shared__ __align__(16) unsigned char sht_mem[];
+  __shared__ int n_sur, n_acc, n_acc_done;
+  const int r = md - 1, md2 = md * md;
+  const int lw = SHT_TW + 2 * r, lh = SHT_TH + 2 * r, la = lw * lh;
+  double* ts = reinterpret_cast<double*>(sht_mem);                                    // [lh][lw] scores (-1 outside the image)
+  unsigned short* wit = reinterpret_cast<unsigned short*>(ts + la);                   // [TH][TW] witness: index into the staged area
+  unsigned short* sur = wit + SHT_TW * SHT_TH;                                        // [TW*TH] pixels that need the whole disc
+  unsigned short* acc = sur + SHT_TW * SHT_TH;                                        // [la] accepted pixels whose disc is to be stamped
+  uint8_t* tq = reinterpret_cast<uint8_t*>(acc + la);                                 // [lh][lw] states
+  int8_t* taps = reinterpret_cast<int8_t*>(tq + ((la + 15) & ~15));                   // [ntaps][2] offsets of the open disc
+  const int tid = threadIdx.x;
+  const int x0 = (int)blockIdx.x * SHT_TW - offx, y0 = (int)blockIdx.y * SHT_TH - offy;
+  constexpr int PPT = SHT_TW * SHT_TH / SHT_THREADS;  // interior pixels per thread
+  // ---- is there anything to decide in this tile?  (first pass: states do not exist yet)
+  if (!first_pass) {
+    bool und = false;
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      const int i = tid + k * SHT_THREADS, gx = x0 + (i % SHT_TW), gy = y0 + (i / SHT_TW);
+      und |= gx >= 0 && gx < w && gy >= 0 && gy < h && state[(size_t)gy * w + gx] == 1;
+    }
+    if (!__syncthreads_or(und)) return;
+  }
+  if (tid == 0) { n_sur = 0; n_acc = 0; n_acc_done = 0; }
+  for (int i = tid; i < 2 * ntaps; i += SHT_THREADS) taps[i] = taps_g[i];
+  const double thr = __longlong_as_double((long long)*max_bits) * quality;
+  __syncthreads();
+  // ---- stage scores and states of the tile and its halo; accepted pixels go on the stamp list
+  for (int i = tid; i < la; i += SHT_THREADS) {
+    const int ly = i / lw, lx = i - ly * lw;
+    const int gx = x0 + lx - r, gy = y0 + ly - r;
+    const bool in = gx >= 0 && gx < w && gy >= 0 && gy < h;
+    const double sc = in ? score[(size_t)gy * w + gx] : -1.0;
+    uint8_t st;
+    if (first_pass) st = (in && sc >= thr) ? 1 : 0;
+    else st = in ? state[(size_t)gy * w + gx] : 0;
+    ts[i] = sc;
+    tq[i] = st;
+    if (st == 2) acc[atomicAdd(&n_acc, 1)] = (unsigned short)i;
+  }
+  for (int i = tid; i < SHT_TW * SHT_TH; i += SHT_THREADS) wit[i] = SHT_NONE;
+  __syncthreads();
+  const int g16 = tid >> 4, l16 = tid & 15, gsh = (g16 & 3) * 16;
+  for (int round = 0; round < max_rounds; ++round) {
+    // ---- (R) stamp the discs of the pixels accepted since the last stamp
+    const int a0 = n_acc_done, a1 = n_acc;
+    __syncthreads();
+    if (tid == 0) { n_acc_done = a1; n_sur = 0; }
+    for (int e = a0 + g16; e < a1; e += SHT_THREADS / 16) {
+      const int ai = acc[e], ay = ai / lw, ax = ai - ay * lw;
+      const double sa = ts[ai];
+      for (int k = l16; k < ntaps; k += 16) {
+        const int qx = ax + taps[2 * k], qy = ay + taps[2 * k + 1];
+        if (qx < 0 || qx >= lw || qy < 0 || qy >= lh) continue;
+        const int qi = qy * lw + qx;
+        if (tq[qi] == 1 && ts[qi] < sa) tq[qi] = 3;
+      }
+    }
+    __syncthreads();
+    // ---- witnesses: keep, reject by, or replace (eight neighbours first)
+    bool changed = a1 > a0;
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+      const int i = tid + k * SHT_THREADS;
+      const int cy = i / SHT_TW + r, cx = i % SHT_TW + r, ci = cy * lw + cx;
+      if (tq[ci] != 1) continue;
+      const double s = ts[ci];
+      const unsigned wi = wit[i];
+      if (wi != SHT_NONE) {
+        const uint8_t ws = tq[wi];
+        if (ws == 1) continue;  // blocked by a live pixel: nothing to do this round
+        if (ws == 2) {
+          if (ts[wi] > s) { tq[ci] = 3; changed = true; }  // (R)
+          continue;  // an accepted pixel of EQUAL score blocks for good (a tie: the host decides)
+        }
+      }
+      // the witness is gone (or there never was one): strongest live neighbour with a score >= s
+      int best = -1;
+      double bs = -1.0;
+      if (r >= 1) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            if (dx * dx + dy * dy >= md2) continue;  // min_dist 2: the diagonal neighbours are outside the disc
+            const int qi = ci + dy * lw + dx;
+            const uint8_t st = tq[qi];
+            const double sq = ts[qi];
+            if ((st == 1 || st == 2) && sq >= s && sq > bs) { bs = sq; best = qi; }
+          }
+      }
+      if (best >= 0) {
+        wit[i] = (unsigned short)best;
+        changed = true;
+        if (tq[best] == 2 && bs > s) tq[ci] = 3;
+      } else {
+        sur[atomicAdd(&n_sur, 1)] = (unsigned short)i;
+      }
+    }
+    __syncthreads();
+    // ---- the whole disc for the pixels without a neighbouring witness, sixteen lanes per pixel
+    const int nsur = n_sur;
+    for (int base = 0; base < nsur; base += SHT_THREADS / 16) {
+      const int e = base + g16;
+      const bool live = e < nsur;
+      const int i = live ? sur[e] : 0;
+      const int cy = i / SHT_TW + r, cx = i % SHT_TW + r, ci = cy * lw + cx;
+      const double s = ts[ci];
+      int best = -1;
+      double bs = -1.0;
+      if (live)
+        for (int k = l16; k < ntaps; k += 16) {
+          const int qi = ci + taps[2 * k + 1] * lw + taps[2 * k];  // inside the staged area: the halo is as wide as the disc
+          const uint8_t st = tq[qi];
+          const double sq = ts[qi];
+          if ((st == 1 || st == 2) && sq >= s && sq > bs) { bs = sq; best = qi; }
+        }
+      // strongest blocker over the sixteen lanes (score, then index, so that every lane agrees)
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o, 16);
+        const int ob = __shfl_xor(best, o, 16);
+        if (os > bs || (os == bs && ob > best)) { bs = os; best = ob; }
+      }
+      if (live && l16 == 0) {
+        if (best >= 0) {
+          wit[i] = (unsigned short)best;
+          if (tq[best] == 2 && bs > s) tq[ci] = 3;
+        } else {
+          tq[ci] = 2;  // (A): nothing live in the disc reaches its score
+          acc[atomicAdd(&n_acc, 1)] = (unsigned short)ci;
+        }
+      }
+      (void)gsh;
+    }
+    changed |= nsur > 0;
+    if (!__syncthreads_or(changed)) break;
+  }
+  __syncthreads();
+  // ---- the tile's own pixels go back (the halo belongs to the neighbours)
+#pragma unroll
+  for (int k = 0; k < PPT; k++) {
+    const int i = tid + k * SHT_THREADS;
+    const int gx = x0 + (i % SHT_TW), gy = y0 + (i / SHT_TW);
+    if (gx >= 0 && gx < w && gy >= 0 && gy < h) state[(size_t)gy * w + gx] = tq[(i / SHT_TW + r) * lw + (i % SHT_TW) + r];
+  }
+}
+static size_t shi_tile_lds(int md, int ntaps) {
+  const int r = md - 1;
+  const size_t la = (size_t)(SHT_TW + 2 * r) * (SHT_TH + 2 * r);
+  return la * 8 + (size_t)SHT_TW * SHT_TH * 2 * 2 + la * 2 + ((la + 15) & ~(size_t)15) + (size_t)2 * ntaps + 32;
+}
+
 // ---- work-list sweeps -------------------------------------------------------------------------------
 // After the first (tiled, all-pixel) sweep about a third of the candidates are still undecided and the
 // dependency chains need ~30 more sweeps.  Those run on a compact list of undecided pixel indices:
@@ -710,6 +886,28 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   if (rc) return rc;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   prof_begin(c, KID_SHI_FIXPOINT);  // init + dense sweeps + work-list sweeps + tail + compaction
+  // SFMX_SHI_MODE=tile[,passes[,rounds]]: the tile-resident fixpoint (k_shi_tile) instead of the sweep schedule below
+  static int tile_passes = 0, tile_rounds = 64;
+  static const bool tile_parsed = [] {
+    if (const char* e = getenv("SFMX_SHI_MODE")) {
+      int a = 3, b = 64;
+      if (strncmp(e, "tile", 4) == 0) {
+        tile_passes = 3;
+        if (sscanf(e, "tile,%d,%d", &a, &b) >= 1) { tile_passes = a < 1 ? 1 : (a > 16 ? 16 : a); tile_rounds = b < 1 ? 1 : b; }
+      }
+    }
+    return true;
+  }();
+  (void)tile_parsed;
+  if (tile_passes > 0) {
+    const size_t lds = shi_tile_lds(min_dist, c->wl_ntaps);
+    for (int pass = 0; pass < tile_passes; ++pass) {
+      const int offx = (pass & 1) ? SHT_TW / 2 : 0, offy = (pass & 1) ? SHT_TH / 2 : 0;  // odd passes: the tile grid shifted by half a tile
+      dim3 gt((p->w + offx + SHT_TW - 1) / SHT_TW, (p->h + offy + SHT_TH - 1) / SHT_TH);
+      k_shi_tile<<<gt, SHT_THREADS, lds, c->stream>>>(c->d[0].as<double>(), p->w, p->h, min_dist, d_flag, d_max, quality, pass == 0 ? 1 : 0, offx, offy,
+                                                     c->wl[3].as<int8_t>(), c->wl_ntaps, tile_rounds);
+    }
+  } else {
   k_shi_init<<<g, 256, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_max, quality, d_flag, c->wl[2].as<int>(), SHI_LIST_SWEEPS + 2);
   // Sweep 1 over all pixels (LDS tiles), then a fixed number of work-list sweeps.  The fixpoint is normally
   // reached after ~30 sweeps; later sweeps see an empty list and cost ~2 us, and stopping before the
@@ -745,6 +943,7 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
     if (tail_sweeps > 0)
       k_shi_list_tail<<<1, 1024, 0, c->stream>>>(c->d[0].as<double>(), p->w, p->h, d_flag, c->wl[3].as<int8_t>(), c->wl_ntaps,
                                                  (list_sweeps & 1) ? list1 : list0, (list_sweeps & 1) ? list0 : list1, counts + list_sweeps, tail_sweeps);
+  }
   }
   k_flag_row_count<<<p->h, 256, 0, c->stream>>>(d_flag, p->w, d_rows, d_rows_all);
   // header in d[1]: [0] max score bits (8 B) | [8] #survivors (4 B) | [12] #candidates (4 B)
@@ -797,6 +996,15 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   uint32_t* d_xy = c->d[3].as<uint32_t>();
   int32_t* d_full = reinterpret_cast<int32_t*>(d_xy + cap);
 
+  if (shi_tile_lds(min_dist, c->wl_ntaps) > 64 * 1024) {  // large discs: the tile kernel needs the dynamic-LDS opt-in (per device, once)
+    static std::mutex attr_mu;
+    static bool attr_set[64] = {};
+    std::lock_guard<std::mutex> lk(attr_mu);
+    if (!attr_set[c->device & 63]) {
+      SFMX_HIP(c, hipFuncSetAttribute((const void*)k_shi_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      attr_set[c->device & 63] = true;
+    }
+  }
   static const bool no_graph = getenv("SFMX_NO_GRAPH") != nullptr;
   ShiGraphKey key;
   memset(&key, 0, sizeof key);

@@ -465,6 +465,370 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
   }
 }
 
+// ================================================================================================ K tracks per wavefront
+// The step of one track keeps only 5 lanes busy in its ordered sums, 3 in its 2x2 solve and none in its loop control -- half of
+// the ~4 000 cycles of an lk_step (profiles/r02_klt_stamps.txt).  k_klt_track_multi gives each of K tracks a GROUP of G = 64 / K
+// lanes of one wavefront: the 121 add instructions of the ordered sums, the division sequence of the solve, the stop test and
+// the loop control are issued once for all K tracks, and the sample / product phases run ceil(work / G) rounds.  Every
+// arithmetic expression is the single-track kernel's (the reference's), only the lane that evaluates it changes.
+//   * per-track state (estimate, level offset, window origin, activity) lives REPLICATED in the lanes of the track's group, so
+//     the code reads like the one-track kernel; wave-uniform control flow (__any over the groups) decides what is executed;
+//   * LDS per track: both staged windows as u8 (2 x 1.25 KB instead of 2 x 5.4 KB of f32: the conversion moves into the
+//     sample, one unaligned 16-bit LDS read per pixel pair), the two sample grids, the products, the tap tables: 12 KB, i.e.
+//     12 tracks per CU instead of 7;
+//   * cross-lane traffic of the solve by DPP inside the group's first quad, the step back to the group through LDS.
+template <int r>
+struct KltLdsM {
+  static constexpr int side = 2 * r + 1, npix = side * side, npad = (npix + 1) & ~1;
+  static constexpr int NCAN = 2 * r + 3, GS = NCAN + 1;
+  static constexpr int RS = 40;  // bytes per window row: 32 pixels + 8 (8-byte aligned rows, consecutive rows 10 banks apart)
+  static constexpr size_t o_win0 = 0, o_win1 = (size_t)KLT_P * RS;
+  static constexpr size_t o_g1 = (size_t)2 * KLT_P * RS;
+  static constexpr size_t o_g0 = o_g1 + (size_t)GS * GS * 8;
+  static constexpr size_t o_prod = o_g0 + (size_t)GS * GS * 8;
+  static constexpr size_t o_tapf = (o_prod + (size_t)5 * npad * 8 + 15) & ~(size_t)15;  // double2 {f, 1-f} [2 axes][16]
+  static constexpr size_t o_tapo = o_tapf + (size_t)2 * 16 * 16;                         // int [2][16]
+  static constexpr size_t o_xtapf = o_tapo + (size_t)2 * 16 * 4;                         // double2 [2 kinds][2 axes][16]
+  static constexpr size_t o_xtapo = o_xtapf + (size_t)2 * 2 * 16 * 16;                   // int [2][2][16]
+  static constexpr size_t o_step = o_xtapo + (size_t)2 * 2 * 16 * 4;                     // double [2]: the step, for the whole group
+  static constexpr size_t bytes = (o_step + 16 + 15) & ~(size_t)15;
+  static constexpr int NS1 = NCAN * NCAN - 4;  // I1 on the grid without its four corners (no pixel has a diagonal neighbour)
+  static constexpr int NS = NS1 + npix;        // + I0 on the grid's centre
+};
+
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+
+template <int RS, int G>
+__device__ __forceinline__ void stage_windows_u8(const uint8_t* __restrict__ img0, const uint8_t* __restrict__ img1, int w, int h, int ox,
+                                                 int oy, uint8_t* __restrict__ win0, uint8_t* __restrict__ win1, int gl) {
+  if (ox >= 0 && oy >= 0 && ox + KLT_P <= w && oy + KLT_P <= h) {  // the usual case: 16-byte chunks, all loads before the stores
+    constexpr int NC = 64 / G;
+    uint32_t va[NC][4], vb[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int chunk = gl + G * c, row = chunk >> 1, c0 = (chunk & 1) * 16;
+      const size_t off = (size_t)(oy + row) * w + ox + c0;
+      const u32_unaligned* a = reinterpret_cast<const u32_unaligned*>(img0 + off);
+      const u32_unaligned* b = reinterpret_cast<const u32_unaligned*>(img1 + off);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { va[c][k] = a[k]; vb[c][k] = b[k]; }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int chunk = gl + G * c, row = chunk >> 1, c0 = (chunk & 1) * 16;
+      uint2* d0 = reinterpret_cast<uint2*>(win0 + row * RS + c0);
+      uint2* d1 = reinterpret_cast<uint2*>(win1 + row * RS + c0);
+      d0[0] = make_uint2(va[c][0], va[c][1]); d0[1] = make_uint2(va[c][2], va[c][3]);
+      d1[0] = make_uint2(vb[c][0], vb[c][1]); d1[1] = make_uint2(vb[c][2], vb[c][3]);
+    }
+    return;
+  }
+  for (int idx = gl; idx < KLT_P * KLT_P; idx += G) {  // window over the image border: zero outside (never weighted, T:188)
+    const int px = idx % KLT_P, py = idx / KLT_P;
+    const int gx = ox + px, gy = oy + py;
+    const bool ok = gx >= 0 && gx < w && gy >= 0 && gy < h;
+    const size_t off = ok ? (size_t)gy * w + gx : 0;
+    const uint8_t a = img0[off], b = img1[off];
+    win0[py * RS + px] = ok ? a : (uint8_t)0;
+    win1[py * RS + px] = ok ? b : (uint8_t)0;
+  }
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+template <int r, int K, bool STAMP>
+__global__ __launch_bounds__(64) void k_klt_track_multi(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels, int iters,
+                                                        double fb_thresh, double* __restrict__ xy_fwd, double* __restrict__ xy_back,
+                                                        uint8_t* __restrict__ keep, unsigned long long* __restrict__ step_counter,
+                                                        unsigned long long* __restrict__ stamps, int wave_prio) {
+  if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
+  else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+  using L = KltLdsM<r>;
+  constexpr int G = 64 / K;
+  static_assert(K == 1 || K == 2 || K == 4, "a group is a whole number of 16-lane DPP rows");
+  constexpr int side = L::side, npix = L::npix, npad = L::npad, NCAN = L::NCAN, GS = L::GS, RS = L::RS;
+  static_assert(NCAN <= 16, "the grid slots of an axis sit in one DPP row");
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+  auto stamp = [&](int k) {
+    if (STAMP) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tph[k] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (STAMP) tlast = __builtin_amdgcn_s_memtime();
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x, g = lane / G, gl = lane % G;
+  unsigned char* base = smem + (size_t)g * L::bytes;
+  uint8_t* win0 = base + L::o_win0;
+  uint8_t* win1 = base + L::o_win1;
+  double* G1 = reinterpret_cast<double*>(base + L::o_g1);
+  double* G0 = reinterpret_cast<double*>(base + L::o_g0);
+  double* prod = reinterpret_cast<double*>(base + L::o_prod);
+  double2* tapf = reinterpret_cast<double2*>(base + L::o_tapf);
+  int* tapo = reinterpret_cast<int*>(base + L::o_tapo);
+  double2* xtapf = reinterpret_cast<double2*>(base + L::o_xtapf);
+  int* xtapo = reinterpret_cast<int*>(base + L::o_xtapo);
+  double* stepv = reinterpret_cast<double*>(base + L::o_step);
+  const int track = blockIdx.x * K + g;
+  const bool valid = track < n;
+  // the samples of this lane, fixed for the whole kernel: I1 at grid rows 1..side (all columns), then row 0 and row NCAN-1
+  // (columns 1..side), then I0 at the centre points.  Packed: column slot | row slot << 5 | I0 << 10 | has-a-sample << 11.
+  constexpr int SR = (L::NS + G - 1) / G;
+  auto sample_desc = [&](int k) -> int {  // a handful of integer operations per sample; a table of them would cost SR registers
+    int e = gl + G * k;
+    const bool ok = e < L::NS;
+    if (!ok) e = 0;
+    int cd, rd, i0 = 0;
+    if (e < side * NCAN) { rd = 1 + e / NCAN; cd = e % NCAN; }
+    else if (e < side * NCAN + side) { rd = 0; cd = 1 + (e - side * NCAN); }
+    else if (e < L::NS1) { rd = NCAN - 1; cd = 1 + (e - side * NCAN - side); }
+    else { i0 = 1; rd = 1 + (e - L::NS1) / side; cd = 1 + (e - L::NS1) % side; }
+    return cd | (rd << 5) | (i0 << 10) | ((ok ? 1 : 0) << 11);
+  };
+  const double p0x = valid ? xy_in[2 * track] : 0.0, p0y = valid ? xy_in[2 * track + 1] : 0.0;
+  double px = p0x, py = p0y;
+  unsigned int steps = 0, slow_steps = 0;
+  // lane roles of the tap phase: a 16-lane row per axis.  G >= 32: row 0 of the group the x axis, row 1 the y axis, in one pass;
+  // G == 16: the group's only row takes the axes one after the other
+  constexpr int NPASS = G >= 32 ? 1 : 2;
+  const int dt = gl & 15;
+  const bool tap_role = G >= 32 ? gl < 32 : true;
+
+  for (int dir = 0; dir < 2; ++dir) {
+    for (int l = levels - 1; l >= 0; --l) {
+      const uint8_t* img0 = dir == 0 ? A.px[l] : B.px[l];
+      const uint8_t* img1 = dir == 0 ? B.px[l] : A.px[l];
+      const int w = A.w[l], h = A.h[l];
+      const double scale = 1.0 / (double)(1 << l);
+      const double plx = px * scale, ply = py * scale;
+      double dlx = 0.0, dly = 0.0;
+      int ox = (int)0x7fffff00, oy = (int)0x7fffff00;  // no window staged yet
+      bool active = valid;                             // this track still iterates on this level (uniform inside a group)
+      for (int it = 0; it < iters; ++it) {
+        if (!__any(active)) break;
+        const double x = plx + dlx, y = ply + dly;
+        stamp(5);  // level / loop bookkeeping
+        const int bx = book_floor(x), by = book_floor(y);
+        const bool touches = (bx + r + 3 >= 0) && (bx - r - 2 < w) && (by + r + 3 >= 0) && (by - r - 2 < h);
+        if (active && !touches) {  // every sample is 0.0 (T:188) => step {0,0} (T:452) => the level ends (T:416); nothing to read
+          ++steps;
+          active = false;
+        }
+        {
+          const bool covered = (bx - r - 2 >= ox) && (bx + r + 3 < ox + KLT_P) && (by - r - 2 >= oy) && (by + r + 3 < oy + KLT_P);
+          const bool need = active && !covered;
+          if (__any(need)) {
+            if (need) {
+              ox = bx - (KLT_P / 2 - 1);
+              oy = by - (KLT_P / 2 - 1);
+            }
+            __syncthreads();
+            if (need) stage_windows_u8<RS, G>(img0, img1, w, h, ox, oy, win0, win1, gl);
+            __syncthreads();
+          }
+        }
+        stamp(0);  // window staging
+        // ---- coordinate taps of the grid slots and the bitwise on-grid test of the reference's neighbour coordinates (see
+        // k_klt_track).  mis_*: bit d+r set = that neighbour of pixel offset d needs a sample of its own.
+        unsigned mis_px = 0, mis_mx = 0, mis_py = 0, mis_my = 0;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+          const int axis = G >= 32 ? ((gl >> 4) & 1) : pass;
+          const double cv = slot_coord<r>(axis ? y : x, min(dt, NCAN - 1));
+          const long long cbits = __double_as_longlong(cv);
+          const long long next_bits = dpp_i64<0x101>(cbits);  // row_shl:1 = lane+1 (every lane enabled: see k_klt_track)
+          const long long prev_bits = dpp_i64<0x111>(cbits);  // row_shr:1 = lane-1
+          const bool inner = tap_role && dt >= 1 && dt <= side;
+          const bool bad_p = inner & (__double_as_longlong(cv + 1) != next_bits);
+          const bool bad_m = inner & (__double_as_longlong(cv - 1) != prev_bits);
+          const unsigned long long bp = __ballot(bad_p), bm = __ballot(bad_m);
+          constexpr unsigned M = (1u << side) - 1u;
+          if (G >= 32) {
+            mis_px = (unsigned)(bp >> (g * G + 1)) & M;  mis_mx = (unsigned)(bm >> (g * G + 1)) & M;
+            mis_py = (unsigned)(bp >> (g * G + 17)) & M; mis_my = (unsigned)(bm >> (g * G + 17)) & M;
+          } else if (pass == 0) {
+            mis_px = (unsigned)(bp >> (g * G + 1)) & M;  mis_mx = (unsigned)(bm >> (g * G + 1)) & M;
+          } else {
+            mis_py = (unsigned)(bp >> (g * G + 1)) & M;  mis_my = (unsigned)(bm >> (g * G + 1)) & M;
+          }
+          if (tap_role && dt < NCAN) {
+            const Tap tp = make_tap(cv, axis ? h : w, axis ? oy : ox);
+            const bool ok = tp.m != 0.0;
+            tapf[axis * 16 + dt] = make_double2(tp.f, ok ? 1 - tp.f : 0.0);
+            tapo[axis * 16 + dt] = tp.l * (axis ? RS : 1);  // byte offset of the tap's row / column in a window
+          }
+          if (bad_p | bad_m) {
+            const double ce = bad_p ? cv + 1 : cv - 1;
+            const Tap tp = make_tap(ce, axis ? h : w, axis ? oy : ox);
+            const int e = (bad_p ? 0 : 32) + axis * 16 + (dt - 1);
+            xtapf[e] = make_double2(tp.f, tp.m != 0.0 ? 1 - tp.f : 0.0);
+            xtapo[e] = tp.l * (axis ? RS : 1);
+            if (bad_p & bad_m) {
+              const Tap tq = make_tap(cv - 1, axis ? h : w, axis ? oy : ox);
+              xtapf[32 + axis * 16 + (dt - 1)] = make_double2(tq.f, tq.m != 0.0 ? 1 - tq.f : 0.0);
+              xtapo[32 + axis * 16 + (dt - 1)] = tq.l * (axis ? RS : 1);
+            }
+          }
+        }
+        __syncthreads();
+        // ---- I1 on the grid and I0 on its centre (T:183-198, rows first), in batches of up to five samples per lane: all tap
+        // reads, then all pixel reads, then the arithmetic, then the stores
+        for (int k0 = 0; k0 < SR; k0 += 5) {
+          constexpr int NBmax = 5;
+          double2 fx[NBmax], fy[NBmax];
+          int po[NBmax], sd[NBmax];
+#pragma unroll
+          for (int k = 0; k < NBmax; k++) {
+            sd[k] = sample_desc(k0 + k < SR ? k0 + k : SR - 1);
+            if (k0 + k >= SR) sd[k] &= ~(1 << 11);  // past the last round: computed, not stored
+            const int cd = sd[k] & 31, rd = (sd[k] >> 5) & 31;
+            fx[k] = tapf[cd];
+            fy[k] = tapf[16 + rd];
+            po[k] = tapo[cd] + tapo[16 + rd];
+          }
+          unsigned pa[NBmax], pb[NBmax];
+#pragma unroll
+          for (int k = 0; k < NBmax; k++) {
+            const uint8_t* p = (((sd[k] >> 10) & 1) ? win0 : win1) + po[k];
+            pa[k] = *reinterpret_cast<const u16_unaligned*>(p);
+            pb[k] = *reinterpret_cast<const u16_unaligned*>(p + RS);
+          }
+          double val[NBmax];
+#pragma unroll
+          for (int k = 0; k < NBmax; k++) {
+            const double v00 = (double)(pa[k] & 0xffu), v10 = (double)(pa[k] >> 8), v01 = (double)(pb[k] & 0xffu), v11 = (double)(pb[k] >> 8);
+            const double v0 = v00 * fx[k].y + v10 * fx[k].x;
+            const double v1 = v01 * fx[k].y + v11 * fx[k].x;
+            val[k] = v0 * fy[k].y + v1 * fy[k].x;
+          }
+#pragma unroll
+          for (int k = 0; k < NBmax; k++)
+            if ((sd[k] >> 11) & 1) (((sd[k] >> 10) & 1) ? G0 : G1)[((sd[k] >> 5) & 31) * GS + (sd[k] & 31)] = val[k];
+        }
+        __syncthreads();
+        stamp(1);  // coordinate check + grid
+        // ---- per-pixel products (T:440-449) from the grid
+        const bool any_mis = (mis_px | mis_mx | mis_py | mis_my) != 0u;  // uniform inside a group
+        if (active && any_mis) ++slow_steps;
+        constexpr int PP = (npix + G - 1) / G;
+        for (int q0 = 0; q0 < PP; q0 += 4) {
+          constexpr int QB = 4;
+          double gxp[QB], gxm[QB], gyp[QB], gym[QB], gcc[QB], irf[QB];
+#pragma unroll
+          for (int q = 0; q < QB; q++)
+            if (q0 + q < PP) {
+              const int pix = gl + G * (q0 + q) < npix ? gl + G * (q0 + q) : 0;
+              const int i = pix / side, j = pix % side;  // dy = i - r (outer), dx = j - r (inner)
+              const double* gc1 = G1 + (i + 1) * GS + (j + 1);
+              gxp[q] = gc1[1]; gxm[q] = gc1[-1]; gyp[q] = gc1[GS]; gym[q] = gc1[-GS]; gcc[q] = gc1[0];
+              irf[q] = G0[(i + 1) * GS + (j + 1)];
+            }
+          if (any_mis) {  // neighbours that are not grid points: sampled with the taps the tap phase wrote for them
+            auto lerp = [&](const double2& fxx, const double2& fyy, int off) {
+              const uint8_t* p = win1 + off;
+              const unsigned a = *reinterpret_cast<const u16_unaligned*>(p), b = *reinterpret_cast<const u16_unaligned*>(p + RS);
+              const double v0 = (double)(a & 0xffu) * fxx.y + (double)(a >> 8) * fxx.x;
+              const double v1 = (double)(b & 0xffu) * fxx.y + (double)(b >> 8) * fxx.x;
+              return v0 * fyy.y + v1 * fyy.x;
+            };
+#pragma unroll
+            for (int q = 0; q < QB; q++)
+              if (q0 + q < PP) {
+                const int pix = gl + G * (q0 + q) < npix ? gl + G * (q0 + q) : 0;
+                const int i = pix / side, j = pix % side;
+                if ((mis_px >> j) & 1u) gxp[q] = lerp(xtapf[j], tapf[16 + i + 1], xtapo[j] + tapo[16 + i + 1]);
+                if ((mis_mx >> j) & 1u) gxm[q] = lerp(xtapf[32 + j], tapf[16 + i + 1], xtapo[32 + j] + tapo[16 + i + 1]);
+                if ((mis_py >> i) & 1u) gyp[q] = lerp(tapf[j + 1], xtapf[16 + i], tapo[j + 1] + xtapo[16 + i]);
+                if ((mis_my >> i) & 1u) gym[q] = lerp(tapf[j + 1], xtapf[48 + i], tapo[j + 1] + xtapo[48 + i]);
+              }
+          }
+#pragma unroll
+          for (int q = 0; q < QB; q++)
+            if (q0 + q < PP) {
+              const int pix = gl + G * (q0 + q);
+              if (pix < npix) {
+                const double Ix = 0.5 * (gxp[q] - gxm[q]), Iy = 0.5 * (gyp[q] - gym[q]), err = irf[q] - gcc[q];
+                prod[0 * npad + pix] = Ix * Ix;
+                prod[1 * npad + pix] = Ix * Iy;
+                prod[2 * npad + pix] = Iy * Iy;
+                prod[3 * npad + pix] = Ix * err;
+                prod[4 * npad + pix] = Iy * err;
+              }
+            }
+        }
+        __syncthreads();
+        stamp(2);  // products
+        // ---- ordered sums: lane k < 5 of every group adds accumulator k's products in reference order -- one add instruction
+        // serves the K tracks of the wave
+        double acc = 0.0;
+        if (gl < 5) {
+          const double2* q = reinterpret_cast<const double2*>(prod + gl * npad);
+          constexpr int CH = 16;
+#pragma unroll
+          for (int i0 = 0; i0 < npix / 2; i0 += CH) {
+            double2 v[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+              if (i0 + k < npix / 2) v[k] = q[i0 + k];
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+              if (i0 + k < npix / 2) { acc += v[k].x; acc += v[k].y; }
+          }
+          if (npix & 1) acc += prod[gl * npad + npix - 1];
+        }
+        stamp(3);  // ordered sums
+        // ---- 2x2 solve (T:451-459) in the first quad of every group: the five sums by DPP, the three divisions in lanes 0..2
+        // of ONE division sequence, the step back to the whole group through LDS
+        const double A00 = dpp_f64<0x00>(acc), A01 = dpp_f64<0x55>(acc), A11 = dpp_f64<0xAA>(acc), b0 = dpp_f64<0xFF>(acc);
+        const double b1 = dpp_f64<0x00>(dpp_f64<0x104>(acc));  // row_shl:4 brings lane 4's sum to lane 0, then to its quad
+        const double detA = A00 * A11 - A01 * A01;
+        const bool singular = fabs(detA) < 1e-9;
+        const double num = gl == 0 ? A11 : (gl == 1 ? -A01 : A00);
+        const double quo = num / detA;
+        const double inv00 = dpp_f64<0x00>(quo), inv01 = dpp_f64<0x55>(quo), inv11 = dpp_f64<0xAA>(quo);
+        const double sxq = singular ? 0.0 : inv00 * b0 + inv01 * b1;
+        const double syq = singular ? 0.0 : inv01 * b0 + inv11 * b1;
+        if (gl == 0) { stepv[0] = sxq; stepv[1] = syq; }
+        __syncthreads();  // also: the products are consumed, the next step may overwrite them
+        const double sx = stepv[0], sy = stepv[1];
+        if (active) {
+          ++steps;
+          dlx += sx;
+          dly += sy;
+          if (hypot_below(sx, sy, 1e-3)) active = false;
+        }
+        stamp(4);  // 2x2 solve
+      }
+      px = (plx + dlx) * (double)(1 << l);
+      py = (ply + dly) * (double)(1 << l);
+    }
+    if (dir == 0 && gl == 0 && valid) {
+      xy_fwd[2 * track] = px;
+      xy_fwd[2 * track + 1] = py;
+    }
+  }
+  if (gl == 0 && valid) {
+    if (xy_back) {
+      xy_back[2 * track] = px;
+      xy_back[2 * track + 1] = py;
+    }
+    const double fb = sfmx::hypot_glibc(px - p0x, py - p0y);
+    keep[track] = (fb >= fb_thresh) ? 0 : 1;  // T:362: `if (fb >= thresh) continue;`
+    if (step_counter) step_counter[track] = (unsigned long long)steps | ((unsigned long long)slow_steps << 32);  // summed by the host
+    if (STAMP && stamps) {
+      for (int k = 0; k < 6; k++) stamps[8 * track + k] = tph[k];
+      stamps[8 * track + 6] = steps;
+      stamps[8 * track + 7] = slow_steps;
+    }
+  }
+}
+
 template <int r>
 static size_t klt_lds_bytes() { return KltLds<r>::bytes; }
 
@@ -505,21 +869,55 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   make_desc(pa), make_desc(pb), c->h[0].as<double>(), n, cfg->levels, cfg->iters, cfg->fb_thresh,                                         \
       reinterpret_cast<double*>(dbase + o_fwd), reinterpret_cast<double*>(dbase + o_back), reinterpret_cast<uint8_t*>(dbase + o_keep),  \
       reinterpret_cast<unsigned long long*>(dbase + o_steps), d_stamps, klt_prio
+  // Tracks per wavefront.  One (K = 1) while the launch leaves SIMDs free anyway: a lone track per wave has the shortest
+  // chain.  Two once there are more tracks than SIMDs (1 024 on MI355X): the waves of a SIMD then share its issue slots, and a
+  // wave that carries two tracks issues the ordered sums, the solve and the loop control once for both.  SFMX_KLT_K = 0 (the
+  // one-track kernel with f32 windows, the only one for win_radius 7), 1, 2, 4 overrides (A/B and tests; identical results).
+  const int k_env = getenv("SFMX_KLT_K") ? atoi(getenv("SFMX_KLT_K")) : -1;  // read per call: the tests switch it inside one process
+  static const int k2_min = getenv("SFMX_KLT_K2_MIN") ? atoi(getenv("SFMX_KLT_K2_MIN")) : 1024;
+  int K = k_env >= 0 ? k_env : 0;  // measured (profiles/r03_klt_multi_probe.txt): the one-track kernel wins at every track count
+  (void)k2_min;
+  if (r > 6 || (K != 1 && K != 2 && K != 4)) K = 0;
+#define KLT_LAUNCH_M(RR, KK)                                                                                                               \
+  do {                                                                                                                                    \
+    const size_t lds = (size_t)(KK) * KltLdsM<RR>::bytes;                                                                                 \
+    if (stamps_on && RR == 5) k_klt_track_multi<RR, KK, true><<<(n + (KK)-1) / (KK), 64, lds, c->stream>>>(KLT_ARGS);                     \
+    else k_klt_track_multi<RR, KK, false><<<(n + (KK)-1) / (KK), 64, lds, c->stream>>>(KLT_ARGS);                                         \
+  } while (0)
+#define KLT_LAUNCH_K(RR)                         \
+  do {                                           \
+    if (K == 1) KLT_LAUNCH_M(RR, 1);             \
+    else if (K == 2) KLT_LAUNCH_M(RR, 2);        \
+    else KLT_LAUNCH_M(RR, 4);                    \
+  } while (0)
 #define KLT_LAUNCH(RR)                                                                              \
   do {                                                                                              \
     if (stamps_on && RR == 5) k_klt_track<5, true><<<n, 64, klt_lds_bytes<5>(), c->stream>>>(KLT_ARGS); \
     else k_klt_track<RR, false><<<n, 64, klt_lds_bytes<RR>(), c->stream>>>(KLT_ARGS);               \
   } while (0)
-  switch (r) {
-    case 1: KLT_LAUNCH(1); break;
-    case 2: KLT_LAUNCH(2); break;
-    case 3: KLT_LAUNCH(3); break;
-    case 4: KLT_LAUNCH(4); break;
-    case 5: KLT_LAUNCH(5); break;
-    case 6: KLT_LAUNCH(6); break;
-    default: KLT_LAUNCH(7); break;
+  if (K == 0) {
+    switch (r) {
+      case 1: KLT_LAUNCH(1); break;
+      case 2: KLT_LAUNCH(2); break;
+      case 3: KLT_LAUNCH(3); break;
+      case 4: KLT_LAUNCH(4); break;
+      case 5: KLT_LAUNCH(5); break;
+      case 6: KLT_LAUNCH(6); break;
+      default: KLT_LAUNCH(7); break;
+    }
+  } else {
+    switch (r) {
+      case 1: KLT_LAUNCH_K(1); break;
+      case 2: KLT_LAUNCH_K(2); break;
+      case 3: KLT_LAUNCH_K(3); break;
+      case 4: KLT_LAUNCH_K(4); break;
+      case 5: KLT_LAUNCH_K(5); break;
+      default: KLT_LAUNCH_K(6); break;
+    }
   }
 #undef KLT_LAUNCH
+#undef KLT_LAUNCH_K
+#undef KLT_LAUNCH_M
 #undef KLT_ARGS
   prof_end(c);
   t.stop();

@@ -1368,7 +1368,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       });
     };
   PhaseMark pm_feeder{"~feeder.. done", t_all};
-  FrameFeeder feeder(ctx, src, cfg.klt, dlevel + 1, dlevel, n_frames, track_lane, prefetch.get(), prefetch_workers + 1, &clk, on_packet);
+  // How many frames ahead of the tracker the corner requests run.  A result takes ~1.5 ms (device fixpoint + tie-order replay on
+  // the resolver thread) and the tracker needs one every ~0.65 ms (it replenishes on nearly every frame): with workers + 1 frames
+  // of lead it waited ~6 ms per 47-frame pass for corners; a result is a few KB, so a deeper queue costs nothing.
+  int prefetch_depth = prefetch_workers + 4;
+  if (const char* e = std::getenv("SFMX_PREFETCH_DEPTH")) prefetch_depth = std::min(64, std::max(1, std::atoi(e)));
+  FrameFeeder feeder(ctx, src, cfg.klt, dlevel + 1, dlevel, n_frames, track_lane, prefetch.get(), prefetch_depth, &clk, on_packet);
   CornerDetector geo_det(ctx, &clk);                                  // loop closure: corners of old keyframe images ...
   std::unordered_map<int, std::shared_ptr<const CornerMemo>> kf_corners;  // ... unless their sequence is already known
   // only the first `loop_corners` corners of a keyframe image are ever asked for again (T:1838-1841): keep that prefix

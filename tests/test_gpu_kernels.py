@@ -635,6 +635,35 @@ def _c4_like_problem(W, P, seed):
     return pw, K, X, ptr, li, uv
 
 
+@pytest.mark.parametrize("shape", [(6, 600), (10, 3000), (6, 40)])
+def test_ba_step_host_solve_equals_device_solve(ctx, shape, monkeypatch):
+    """sfmx_ba_step solves the window's 36 / 60 unknowns on the host core that polls for the result (csrc/hip/solve_host.cpp,
+    the default) or in the last workgroup of the reduction (SFMX_BA_SOLVE=device): same S | b, the same elimination order
+    (dense.hpp:54-93), so dx and the status must agree bit for bit -- with each other and with the oracle -- also where the
+    system is singular (a point cloud behind the cameras: every residual skipped, T:933) and where a pose is NaN."""
+    W, P = shape
+    pw, K, X, ptr, li, uv = _c4_like_problem(W, P, 21)
+    prob = ctx.ba_problem(W, X, ptr, li, uv)
+    a = (K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    behind = pw.copy()
+    behind[:, 11] -= 10.0   # every Xc.z <= 1e-6: S = lambda I + gauge, b = 0: solvable, dx = 0
+    nanpose = pw.copy()
+    nanpose[2, 4] = np.nan
+    for tag, poses in (("regular", pw), ("behind", behind), ("nan", nanpose)):
+        monkeypatch.delenv("SFMX_BA_SOLVE", raising=False)
+        rc_h, dx_h = prob.step(poses, *a)
+        monkeypatch.setenv("SFMX_BA_SOLVE", "device")
+        rc_d, dx_d = prob.step(poses, *a)
+        monkeypatch.delenv("SFMX_BA_SOLVE", raising=False)
+        S, b = prob.build(poses, *a, True)
+        erc, ex = H.solve_gauss(O, "orc", S, b)
+        assert rc_h == rc_d == (0 if erc == 0 else capi.SFMX_ERR_SINGULAR), (tag, rc_h, rc_d, erc)
+        if erc == 0:
+            H.assert_bits_equal(dx_h, ex, f"host solve vs oracle ({tag})", nan_equal=True)
+            H.assert_bits_equal(dx_d, ex, f"device solve vs oracle ({tag})", nan_equal=True)
+    prob.close()
+
+
 def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
     """sfmx_ba_step_sharded (partial build -> [all-reduce] -> damp/gauge kernel -> solve) with one rank must equal the fused
     sfmx_ba_step bit for bit: same sums, no collective reordering with world size 1 -- with no communicator and with a
