@@ -67,6 +67,15 @@ void sfmx_pyramid_destroy(sfmx_ctx* ctx, sfmx_pyramid* pyr);
 int sfmx_pyramid_upload(sfmx_ctx* ctx, sfmx_pyramid* pyr, const uint8_t* host_pixels);
 /* pixels already resident in HBM (device pointer): device copy + build */
 int sfmx_pyramid_set_device(sfmx_ctx* ctx, sfmx_pyramid* pyr, const void* device_pixels);
+/* The same build on the context's SECOND stream (it overlaps with kernels already queued on the first, e.g. the KLT launch of
+ * the previous frame); fetch_level >= 0 also copies that level's pixels to pinned host memory.  Nothing that still reads the
+ * pyramid may be in flight.  sfmx_pyramid_wait orders the context's main stream behind the build (no host wait; calls of THIS
+ * context that take the pyramid do it themselves, another context that reads it must be started after a host-side wait such as
+ * sfmx_pyramid_fetched_level or sfmx_sync); sfmx_pyramid_fetched_level waits for the copy and returns the pixels (*out == NULL
+ * if that level was not fetched). */
+int sfmx_pyramid_set_device_async(sfmx_ctx* ctx, sfmx_pyramid* pyr, const void* device_pixels, int fetch_level);
+int sfmx_pyramid_wait(sfmx_ctx* ctx, sfmx_pyramid* pyr);
+int sfmx_pyramid_fetched_level(sfmx_ctx* ctx, sfmx_pyramid* pyr, int level, const uint8_t** out);
 int sfmx_pyramid_download_level(sfmx_ctx* ctx, const sfmx_pyramid* pyr, int level, uint8_t* host_out);
 int sfmx_pyramid_level_size(const sfmx_pyramid* pyr, int level, int* w, int* h);
 
@@ -169,6 +178,13 @@ int sfmx_ba_build(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, 
  * reference's solve_gauss would throw (the caller then skips BA as T:1076-1078 does). */
 int sfmx_ba_step(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, double fx, double fy,
                  double cx, double cy, double huber, double lambda, double* dx_out);
+/* Optional bracket around the sfmx_ba_step calls of ONE bundle_adjust_window call (T:893-1096: `iters` iterations on the same
+ * window and intrinsics).  For window-sized problems sfmx_ba_begin launches a kernel that stays resident for the whole job, so
+ * that an iteration is a hand-over of poses and a poll for S | b instead of two launches that queue behind the kernels of other
+ * contexts; sfmx_ba_end releases it when the job stops early (SFMX_ERR_SINGULAR).  Results are identical with and without. */
+int sfmx_ba_begin(sfmx_ctx* ctx, sfmx_ba_problem* prob, int iters, double fx, double fy, double cx, double cy, double huber,
+                  double lambda);
+int sfmx_ba_end(sfmx_ctx* ctx, sfmx_ba_problem* prob);
 /* partial sums for point-sharded multi-GPU BA: raw S,b of this problem's points only (no damping);
  * device pointers (valid until the next call on prob) so the caller can all-reduce them in HBM. */
 int sfmx_ba_build_partial(sfmx_ctx* ctx, sfmx_ba_problem* prob, const double* poses_wc, double fx,

@@ -24,9 +24,9 @@ SFMX_OK, SFMX_ERR_INVALID, SFMX_ERR_HIP, SFMX_ERR_NO_DEVICE, SFMX_ERR_SINGULAR, 
 SYMBOLS = [
     "sfmx_ctx_create", "sfmx_ctx_create_prio", "sfmx_ctx_destroy", "sfmx_last_error", "sfmx_sync", "sfmx_ctx_device", "sfmx_ctx_make_current", "sfmx_stream", "sfmx_set_timing", "sfmx_get_timing",
     "sfmx_last_kernel_us", "sfmx_kernel_profile", "sfmx_kernel_profile_name", "sfmx_pyramid_create", "sfmx_pyramid_destroy", "sfmx_pyramid_upload",
-    "sfmx_pyramid_set_device", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
+    "sfmx_pyramid_set_device", "sfmx_pyramid_set_device_async", "sfmx_pyramid_wait", "sfmx_pyramid_fetched_level", "sfmx_pyramid_download_level", "sfmx_pyramid_level_size", "sfmx_shi_tomasi_score",
     "sfmx_shi_tomasi_candidates", "sfmx_shi_tomasi_candidates_pruned", "sfmx_shi_tomasi_fetch_all_keys", "sfmx_klt_track", "sfmx_ransac_score", "sfmx_ransac_score_ex", "sfmx_sampson_mask", "sfmx_ba_create",
-    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_build_partial", "sfmx_ba_step_sharded", "sfmx_ba_step_sharded_elements", "sfmx_solve_dense", "sfmx_posegraph_solve",
+    "sfmx_ba_reset", "sfmx_ba_destroy", "sfmx_ba_build", "sfmx_ba_step", "sfmx_ba_begin", "sfmx_ba_end", "sfmx_ba_build_partial", "sfmx_ba_step_sharded", "sfmx_ba_step_sharded_elements", "sfmx_solve_dense", "sfmx_posegraph_solve",
     "sfmx_comm_get_unique_id", "sfmx_comm_create", "sfmx_comm_destroy", "sfmx_comm_rank", "sfmx_comm_world", "sfmx_shard_range",
     "sfmx_comm_allreduce_f64", "sfmx_comm_allreduce_u64_max",
     "sfmx_debug_hypot", "sfmx_debug_divsqrt", "sfmx_debug_klt_slow_steps",
@@ -141,6 +141,14 @@ class BaProblem:
         if rc not in (SFMX_OK, SFMX_ERR_SINGULAR):
             self.ctx._chk(rc)
         return rc, dx
+
+    def begin(self, iters, fx, fy, cx, cy, huber, lam):
+        """bracket of a job of `iters` step() calls (resident kernel for window-sized problems)"""
+        self.ctx._chk(self.ctx.lib.sfmx_ba_begin(self.ctx.h_, self.h_, c_int(iters), c_double(fx), c_double(fy), c_double(cx), c_double(cy),
+                                                 c_double(huber), c_double(lam)))
+
+    def end(self):
+        self.ctx._chk(self.ctx.lib.sfmx_ba_end(self.ctx.h_, self.h_))
 
     def step_sharded(self, comm, poses_wc, fx, fy, cx, cy, huber, lam):
         """point-sharded iteration: partial build, RCCL all-reduce of S|b in HBM, damping + gauge, solve (comm None = 1 rank)"""

@@ -48,6 +48,14 @@ struct sfmx_ba_problem {
   unsigned* ticket = nullptr;  // finished-workgroup counter of the fused reduce + solve (zero between launches)
   hipEvent_t ev_sync = nullptr, ev_exp[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};  // chunked expand / reduce pipeline
   int chunk = 0;                // points per chunk of the contribution-row ring (0: all rows resident)
+  // resident job (k_ba_window_resident): launched by sfmx_ba_begin, fed by sfmx_ba_step, released by sfmx_ba_end
+  bool job_active = false;
+  int job_iters = 0, job_done = 0;
+  unsigned long long job_first_seq = 0;
+  double job_k[6] = {0, 0, 0, 0, 0, 0};  // fx, fy, cx, cy, huber, lambda the kernel was launched with
+  DevBuf job_ctl;                        // BaResidentCtl
+  PinBuf job_cmd;                        // command words (pinned host memory the kernel polls): a ring, one word per job, so that a
+  unsigned job_slot = 0;                 // kernel still leaving on EXIT never sees the next job's commands
 };
 
 // dense.hpp:96-119
@@ -309,15 +317,16 @@ __device__ __forceinline__ void ba_points_body(int W, int P, int MS, const doubl
                                                const int32_t* __restrict__ obs_ptr, const int32_t* __restrict__ obs_li,
                                                const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy,
                                                double huber, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C,
-                                               int wave_prio) {
+                                               int wave_prio, int blk) {
   // the BA iterations are the longest dependent chain of a keyframe: their waves go first where they share a SIMD with
   // the bulk kernels of the other lanes (KLT, hypotheses, corner sweeps)
   if (wave_prio) __builtin_amdgcn_s_setprio(3);
   __shared__ double sp[BA_MAX_W * 12];
   const int tid = threadIdx.x;
+  __syncthreads();  // (a caller that loops over blocks: the previous block's readers of sp are done)
   for (int i = tid; i < W * 12; i += NT) sp[i] = poses[i];
   __syncthreads();
-  const int p0 = blockIdx.x * PTS;
+  const int p0 = blk * PTS;
   if constexpr (PTS * BA_MAX_OBS <= 64 && NT >= 64) {
     ba_point_records_wave<PTS>(p0, P, W, MS, sp, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of);
   } else {
@@ -369,7 +378,7 @@ __device__ __forceinline__ void ba_points_body(int W, int P, int MS, const doubl
   int W, int P, int MS, const double *__restrict__ poses, const double *__restrict__ X, const int32_t *__restrict__ obs_ptr,              \
       const int32_t *__restrict__ obs_li, const double *__restrict__ obs_uv, double fx, double fy, double cx, double cy, double huber,   \
       double *__restrict__ rec, int8_t *__restrict__ slot_of, double *__restrict__ C, int wave_prio
-#define BA_POINTS_PASS W, P, MS, poses, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of, C, wave_prio
+#define BA_POINTS_PASS W, P, MS, poses, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of, C, wave_prio, (int)blockIdx.x
 // The window-sized shape is held to 96 VGPRs (the compiler takes 200 when left alone, 400 B of spills at 96 cost nothing
 // measurable): its four-wave workgroups need room on all four SIMDs of a CU at once, and next to KLT waves (173 VGPRs
 // each, one or two per SIMD) a 200-VGPR wave often finds none -- every launch slower than 60 us in the kernel trace
@@ -761,11 +770,11 @@ __global__ __launch_bounds__(64) void k_solve_regs_stamps(const double* __restri
 // small footprint finds a CU sooner next to KLT workgroups.  The streaming shape that C4 uses is <128, N, 2, 2>: 64 KiB of
 // LDS, half as many barriers per point (C4 reduction 1.14 -> 0.91 ms; <64, N, 4, 3> before).
 template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
-__global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
-                                                   double* __restrict__ S, double* __restrict__ b,
-                                                   unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
-                                                   unsigned long long seq, int wave_prio, const double* init = nullptr, int wg_off = 0,
-                                                   int publish_system = 0) {
+__device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
+                                               double* __restrict__ b, unsigned* __restrict__ ticket, double* __restrict__ work,
+                                               double* __restrict__ host_out, unsigned long long seq, int wave_prio, const double* init,
+                                               int blk, int nblk, int publish_system) {
+  // blk / nblk: this workgroup's element block and how many blocks the launch has (the ticket of the fused solve counts them)
   // init (optional, [D*D + D] in S | b layout, may alias S): the chains start from these values instead of +0.0 -- a shard
   // that continues the running sums of the shard before it (relay mode: the reference's sequence across shards)
   if (wave_prio) __builtin_amdgcn_s_setprio(3);  // see k_ba_points
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
   double (*su)[BAR_TP][BAR_COLS] = reinterpret_cast<double (*)[BAR_TP][BAR_COLS]>(lds + BAR_NBUF * BAR_TP * BAR_COLS);
   const int D = 6 * W, CS = ba_row_stride(W), NE = D * D + D;
   const int tid = threadIdx.x, col = tid % BAR_COLS, q = tid / BAR_COLS;
-  const int e_raw = ((int)blockIdx.x + wg_off) * BAR_COLS + col;  // wg_off: element-sharded launches cover a slice of the blocks
+  const int e_raw = blk * BAR_COLS + col;
   const bool valid = e_raw < NE;
   const int e = valid ? e_raw : NE - 1;
   const bool is_b = e >= D * D;
@@ -902,7 +911,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
     __shared__ int is_last;
     if (tid < BAR_COLS) __threadfence();  // this workgroup's elements are visible device-wide before its ticket is
     __syncthreads();
-    if (tid == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    if (tid == 0) is_last = atomicAdd(ticket, 1u) == (unsigned)nblk - 1u ? 1 : 0;
     __syncthreads();
     if (!is_last) return;
     __threadfence();  // acquire: S | b of every other workgroup
@@ -930,6 +939,104 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
       wave_sync();
       if (tid == 0)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + SOLVE_N + 1), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
+__global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
+                                                   double* __restrict__ S, double* __restrict__ b,
+                                                   unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
+                                                   unsigned long long seq, int wave_prio, const double* init = nullptr, int wg_off = 0,
+                                                   int publish_system = 0) {
+  // wg_off: element-sharded launches cover a slice of the element blocks
+  ba_reduce_body<BAR_TP, SOLVE_N, BAR_NPF, BAR_NBUF>(W, P, C, lambda, damp, S, b, ticket, work, host_out, seq, wave_prio, init,
+                                                     (int)blockIdx.x + wg_off, (int)gridDim.x, publish_system);
+}
+
+// ------------------------------------------------------------------------------------------ resident window BA
+// One BA job of the pipeline is `iters` (5) iterations on the same window, each a host round trip (the SO(3) update needs the
+// platform libm) -- ten launches whose workgroups queue behind the KLT / hypothesis / corner kernels of the other lanes every
+// time: inside the pipeline an iteration took ~80 us against ~25 us with the device to itself.  k_ba_window_resident is
+// launched ONCE per job and stays: its workgroups (one per block of 16 elements of S | b, 84 at 36 unknowns) run the points
+// phase of an iteration (a few 4-point batches each), meet at a device-wide barrier, reduce their element block over all
+// points, the last one publishes S | b into pinned host memory -- and then all of them wait for the host's next command word
+// (the iteration number whose poses it has written into the pinned pose block, or EXIT).  The arithmetic is the two kernels'
+// (the same device functions); only who waits where changes.
+// Every wait is bounded (BAW_SPIN_LIMIT polls, ~0.2 s): a kernel that gives up raises ctl->abort and leaves; the host then
+// reports an error instead of hanging, and nothing ever spins on a device that has lost its host.
+#define BAW_EXIT 0xffffffffffffffffull
+#define BAW_SPIN_LIMIT 400000
+struct BaResidentCtl {          // device memory, zeroed before every launch
+  unsigned arrive;              // barrier between the points and the reduction phase (monotonic)
+  unsigned ticket;              // finished reductions (monotonic)
+  unsigned abort;               // a wait ran out
+  unsigned pad;
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_ba_window_resident(
+    int W, int P, int MS, const double* poses_host, const double* __restrict__ X, const int32_t* __restrict__ obs_ptr,
+    const int32_t* __restrict__ obs_li, const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy, double huber,
+    double lambda, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C, double* __restrict__ S,
+    double* __restrict__ b, BaResidentCtl* ctl, const unsigned long long* cmd_host, double* result_host, unsigned long long first_seq, int max_iters, int wave_prio) {
+  __shared__ unsigned long long s_cmd;
+  __shared__ int s_flag;
+  __shared__ double s_poses[BA_MAX_W * 12];
+  const int tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x;
+  const int D = 6 * W, NE = D * D + D;
+  const int nbatch = (P + BA_PTS - 1) / BA_PTS;
+  for (int it = 0; it < max_iters; ++it) {
+    const unsigned long long want = first_seq + (unsigned long long)it;
+    // ---- the host's command: poses of iteration `want` are in place, or EXIT
+    if (tid == 0) {
+      unsigned long long v = 0;
+      int spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(cmd_host, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (v == want || v == BAW_EXIT) break;
+        if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > BAW_SPIN_LIMIT) { v = BAW_EXIT; atomicExch(&ctl->abort, 1u); break; }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      s_cmd = v;
+    }
+    __syncthreads();
+    if (s_cmd != want) return;
+    // ---- points phase: 4-point batches blk, blk + nblk, ... (records + contribution rows).  The poses change from iteration
+    // to iteration inside this one launch: they are fetched with system-scope loads (never from a cache line of the iteration
+    // before, never hoisted) into LDS, which is what the batches then read
+    for (int i = tid; i < W * 12; i += 256) s_poses[i] = __hip_atomic_load(poses_host + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    for (int bt = blk; bt < nbatch; bt += nblk)
+      ba_points_body<BA_PTS, 256>(W, P, MS, s_poses, X, obs_ptr, obs_li, obs_uv, fx, fy, cx, cy, huber, rec, slot_of, C, wave_prio, bt);
+    // ---- every row is written before any element block is reduced
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+      atomicAdd(&ctl->arrive, 1u);
+      const unsigned target = (unsigned)(it + 1) * (unsigned)nblk;
+      int spins = 0, ok = 1;
+      while (__hip_atomic_load(&ctl->arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > BAW_SPIN_LIMIT) { ok = 0; atomicExch(&ctl->abort, 1u); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      s_flag = ok;
+    }
+    __syncthreads();
+    if (!s_flag) return;
+    __threadfence();
+    // ---- reduction of this workgroup's element block over all points (damping and gauge included, T:1064-1071)
+    ba_reduce_body<64, 0, 2, 2>(W, P, C, lambda, 1, S, b, nullptr, nullptr, nullptr, 0, wave_prio, nullptr, blk, nblk, 0);
+    // ---- the last workgroup to finish hands S | b to the host
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_flag = atomicAdd(&ctl->ticket, 1u) == (unsigned)(it + 1) * (unsigned)nblk - 1u ? 1 : 0;
+    __syncthreads();
+    if (s_flag) {
+      __threadfence();
+      for (int k = tid; k < NE; k += 256) result_host[k] = S[k];  // S | b are contiguous
+      __threadfence_system();
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(result_host + NE), want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -1486,6 +1593,7 @@ extern "C" {
 int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X, const int32_t* obs_ptr, const int32_t* obs_li,
                   const double* obs_uv) {
   SFMX_REQUIRE(c, c && q && W >= 1 && W <= BA_MAX_W && P >= 1 && X && obs_ptr && obs_li && obs_uv);
+  if (q->job_active) (void)sfmx_ba_end(c, q);
   const int R = obs_ptr[P];
   SFMX_REQUIRE(c, R >= 0 && obs_ptr[0] == 0);
   q->W = W; q->P = P; q->R = R;
@@ -1546,8 +1654,11 @@ int sfmx_ba_create(sfmx_ctx* c, int W, int P, const double* X, const int32_t* ob
 
 void sfmx_ba_destroy(sfmx_ctx* c, sfmx_ba_problem* q) {
   if (!q) return;
+  if (q->job_active && c) (void)sfmx_ba_end(c, q);
   if (c) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream); }
   for (auto& b : q->bufs) b.release();
+  q->job_ctl.release();
+  q->job_cmd.release();
   if (q->ev_sync) (void)hipEventDestroy(q->ev_sync);
   for (int k = 0; k < 2; k++) {
     if (q->ev_exp[k]) (void)hipEventDestroy(q->ev_exp[k]);
@@ -1588,9 +1699,84 @@ int sfmx_ba_build_partial(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_w
 // csrc/hip/solve_host.cpp (g++): dense.hpp:54-93 on the host core that polls for the result
 extern "C" int sfmx_host_solve_window(const double* S, const double* b, int n, double* x, double* work);
 
+// A BA job = up to `iters` sfmx_ba_step calls on one problem with the same intrinsics.  sfmx_ba_begin launches the resident kernel
+// (window-sized problems with a 36-unknown system; anything else keeps the two launches per step), sfmx_ba_step then only hands
+// the poses over and polls for S | b, sfmx_ba_end releases the kernel if the job ended early (singular system).  Optional: a
+// step outside a job works as before.  SFMX_BA_RESIDENT=0 switches the mode off (A/B and tests; identical results).
+int sfmx_ba_begin(sfmx_ctx* c, sfmx_ba_problem* q, int iters, double fx, double fy, double cx, double cy, double huber, double lambda) {
+  SFMX_REQUIRE(c, c && q && iters >= 0);
+  if (q->job_active) (void)sfmx_ba_end(c, q);
+  // Opt-in (SFMX_BA_RESIDENT=1): built, bit-exact and tested, but measured SLOWER inside the pipeline than two launches per
+  // iteration (lane B 27.9 ms against 18.6 ms per 47-frame pass, profiles/r03_ab_ba_resident.txt) -- see DESIGN.md 4.4.
+  const char* e = getenv("SFMX_BA_RESIDENT");
+  const char* se = getenv("SFMX_BA_SOLVE");
+  const bool off = !(e && e[0] == '1') || (se && std::string(se) == "device") || getenv("SFMX_BA_NO_POLL") || getenv("SFMX_BA_NO_FUSE");
+  if (off || c->timing || iters < 1 || q->W != 6 || q->chunk != 0 || q->P > BA_MERGED_EXPAND_MAX_P) return SFMX_OK;
+  const int D = 6 * q->W, NE = D * D + D;
+  SFMX_HIP(c, q->job_ctl.ensure(sizeof(BaResidentCtl)));
+  SFMX_HIP(c, q->job_cmd.ensure(16 * 8));
+  q->job_slot = (q->job_slot + 1) & 15;
+  SFMX_HIP(c, c->h[0].ensure((size_t)q->W * 96));
+  SFMX_HIP(c, c->h[1].ensure((size_t)NE * 8 + 32));
+  __atomic_store_n(q->job_cmd.as<unsigned long long>() + q->job_slot, 0ull, __ATOMIC_RELEASE);
+  *reinterpret_cast<volatile unsigned long long*>(c->h[1].as<double>() + NE) = 0;
+  SFMX_HIP(c, hipMemsetAsync(q->job_ctl.p, 0, sizeof(BaResidentCtl), c->stream));
+  q->job_first_seq = c->ba_seq + 1;
+  q->job_iters = iters;
+  q->job_done = 0;
+  const double k[6] = {fx, fy, cx, cy, huber, lambda};
+  memcpy(q->job_k, k, sizeof k);
+  k_ba_window_resident<<<ba_element_blocks(q), 256, 0, c->stream>>>(q->W, q->P, q->MS, c->h[0].as<double>(), q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy,
+                                                                   cx, cy, huber, lambda, q->rec, q->slot_of, q->contrib, q->S, q->b,
+                                                                   q->job_ctl.as<BaResidentCtl>(), q->job_cmd.as<unsigned long long>() + q->job_slot,
+                                                                   c->h[1].as<double>(), q->job_first_seq, iters, ba_wave_prio());
+  SFMX_HIP(c, hipGetLastError());
+  q->job_active = true;
+  c->ba_upload_in_flight = false;  // the kernel is ordered behind the upload on the stream; nothing else touches the staging slab
+  return SFMX_OK;
+}
+int sfmx_ba_end(sfmx_ctx* c, sfmx_ba_problem* q) {
+  SFMX_REQUIRE(c, c && q);
+  if (!q->job_active) return SFMX_OK;
+  if (q->job_done < q->job_iters)  // ended early: the kernel is waiting for a command
+    __atomic_store_n(q->job_cmd.as<unsigned long long>() + q->job_slot, BAW_EXIT, __ATOMIC_RELEASE);
+  q->job_active = false;
+  return SFMX_OK;
+}
+// one step of an active job: poses -> command word -> S | b -> host solve
+static int ba_step_resident(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double* dx_out) {
+  const int D = 6 * q->W, NE = D * D + D;
+  const unsigned long long seq = ++c->ba_seq;  // == job_first_seq + job_done
+  double* hout = c->h[1].as<double>();
+  memcpy(c->h[0].p, poses_wc, (size_t)q->W * 96);
+  __atomic_store_n(q->job_cmd.as<unsigned long long>() + q->job_slot, seq, __ATOMIC_RELEASE);
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(hout + NE);
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) {
+      __atomic_store_n(q->job_cmd.as<unsigned long long>() + q->job_slot, BAW_EXIT, __ATOMIC_RELEASE);
+      q->job_active = false;
+      SFMX_HIP(c, hipStreamSynchronize(c->stream));
+      return sfmx_fail(c, SFMX_ERR_HIP, "BA step result never arrived (resident kernel)", hipSuccess);
+    }
+  }
+  q->job_done++;
+  if (q->job_done >= q->job_iters) q->job_active = false;  // the kernel leaves by itself after its last iteration
+  double work[36 * 37];
+  const int status = sfmx_host_solve_window(hout, hout + (size_t)D * D, D, dx_out, work);
+  return status ? SFMX_ERR_SINGULAR : SFMX_OK;
+}
+
 int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double fx, double fy, double cx, double cy, double huber,
                  double lambda, double* dx_out) {
   SFMX_REQUIRE(c, c && q && poses_wc && dx_out);
+  if (q->job_active) {
+    const double k[6] = {fx, fy, cx, cy, huber, lambda};
+    if (memcmp(k, q->job_k, sizeof k) == 0 && !c->timing) return ba_step_resident(c, q, poses_wc, dx_out);
+    (void)sfmx_ba_end(c, q);  // other parameters than the job was started with: release it, take the plain path
+  }
   const int D = 6 * q->W, NE = D * D + D;
   static const bool no_poll = getenv("SFMX_BA_NO_POLL") != nullptr;
   static const bool no_fuse = getenv("SFMX_BA_NO_FUSE") != nullptr;  // A/B and tests: reduce, solve and publish as separate launches

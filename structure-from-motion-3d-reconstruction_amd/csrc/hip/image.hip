@@ -25,14 +25,24 @@ __global__ void k_downsample2(const uint8_t* __restrict__ src, int sw, int sh, u
   dst[(size_t)y * dw + x] = (uint8_t)(sum / 4);
 }
 
-static int build_levels(sfmx_ctx* c, sfmx_pyramid* p) {
-  if (p->levels > 1) prof_begin(c, KID_PYRAMID);  // all levels of one image = one profile entry
-  struct End { sfmx_ctx* c; ~End() { prof_end(c); } } end{c};
+static int build_levels(sfmx_ctx* c, sfmx_pyramid* p, hipStream_t stream) {
+  const bool prof = stream == c->stream;
+  if (prof && p->levels > 1) prof_begin(c, KID_PYRAMID);  // all levels of one image = one profile entry
+  struct End { sfmx_ctx* c; bool on; ~End() { if (on) prof_end(c); } } end{c, prof};
   for (int l = 1; l < p->levels; l++) {
     if (p->lw[l] <= 0 || p->lh[l] <= 0) continue;
     dim3 b(64, 4), g((p->lw[l] + 63) / 64, (p->lh[l] + 3) / 4);
-    k_downsample2<<<g, b, 0, c->stream>>>(p->base + p->off[l - 1], p->lw[l - 1], p->lh[l - 1], p->base + p->off[l], p->lw[l], p->lh[l]);
+    k_downsample2<<<g, b, 0, stream>>>(p->base + p->off[l - 1], p->lw[l - 1], p->lh[l - 1], p->base + p->off[l], p->lw[l], p->lh[l]);
     SFMX_HIP(c, hipGetLastError());
+  }
+  return SFMX_OK;
+}
+// a pyramid that is still being built on the second stream: the context's main stream waits for it (device side, no host wait)
+int sfmx_pyramid_settle(sfmx_ctx* c, const sfmx_pyramid* p) {
+  sfmx_pyramid* q = const_cast<sfmx_pyramid*>(p);
+  if (q->ready_pending) {
+    SFMX_HIP(c, hipStreamWaitEvent(c->stream, q->ready, 0));
+    q->ready_pending = false;
   }
   return SFMX_OK;
 }
@@ -67,25 +77,66 @@ int sfmx_pyramid_create(sfmx_ctx* c, int w, int h, int levels, sfmx_pyramid** ou
 
 void sfmx_pyramid_destroy(sfmx_ctx* c, sfmx_pyramid* p) {
   if (!p) return;
-  if (c) (void)hipStreamSynchronize(c->stream);
+  if (c) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->copy_stream); }
+  if (p->ready) (void)hipEventDestroy(p->ready);
+  p->fetched.release();
   if (p->base) (void)hipFree(p->base);
   delete p;
 }
 
 int sfmx_pyramid_upload(sfmx_ctx* c, sfmx_pyramid* p, const uint8_t* host_pixels) {
   SFMX_REQUIRE(c, c && p && host_pixels);
+  if (int rc = sfmx_pyramid_settle(c, p)) return rc;
+  p->fetched_level = -1;
   SFMX_HIP(c, hipMemcpyAsync(p->base, host_pixels, (size_t)p->w * p->h, hipMemcpyHostToDevice, c->stream));
-  return build_levels(c, p);
+  return build_levels(c, p, c->stream);
 }
 
 int sfmx_pyramid_set_device(sfmx_ctx* c, sfmx_pyramid* p, const void* device_pixels) {
   SFMX_REQUIRE(c, c && p && device_pixels);
+  if (int rc = sfmx_pyramid_settle(c, p)) return rc;
+  p->fetched_level = -1;
   SFMX_HIP(c, hipMemcpyAsync(p->base, device_pixels, (size_t)p->w * p->h, hipMemcpyDeviceToDevice, c->stream));
-  return build_levels(c, p);
+  return build_levels(c, p, c->stream);
+}
+
+// The same on the context's SECOND stream, so that the pyramid of the next frame is built while the kernels of the current
+// one (KLT) occupy the first; optionally the pixels of one level (the 32x32 descriptor's source) travel to pinned host memory
+// in the same go.  The caller must not have work in flight that still reads this pyramid object.  sfmx_pyramid_wait orders the
+// context's main stream behind the build; sfmx_pyramid_fetched_level waits on the host for the copy and returns the pixels.
+int sfmx_pyramid_set_device_async(sfmx_ctx* c, sfmx_pyramid* p, const void* device_pixels, int fetch_level) {
+  SFMX_REQUIRE(c, c && p && device_pixels && fetch_level < p->levels);
+  if (!p->ready) SFMX_HIP(c, hipEventCreateWithFlags(&p->ready, hipEventDisableTiming));
+  SFMX_HIP(c, hipMemcpyAsync(p->base, device_pixels, (size_t)p->w * p->h, hipMemcpyDeviceToDevice, c->copy_stream));
+  const int rc = build_levels(c, p, c->copy_stream);
+  if (rc) return rc;
+  p->fetched_level = -1;
+  if (fetch_level >= 0) {
+    const size_t nb = (size_t)p->lw[fetch_level] * p->lh[fetch_level];
+    SFMX_HIP(c, p->fetched.ensure(nb > 0 ? nb : 1));
+    if (nb) SFMX_HIP(c, hipMemcpyAsync(p->fetched.p, p->base + p->off[fetch_level], nb, hipMemcpyDeviceToHost, c->copy_stream));
+    p->fetched_level = fetch_level;
+  }
+  SFMX_HIP(c, hipEventRecord(p->ready, c->copy_stream));
+  p->ready_pending = true;
+  return SFMX_OK;
+}
+int sfmx_pyramid_wait(sfmx_ctx* c, sfmx_pyramid* p) {
+  SFMX_REQUIRE(c, c && p);
+  return sfmx_pyramid_settle(c, p);
+}
+int sfmx_pyramid_fetched_level(sfmx_ctx* c, sfmx_pyramid* p, int level, const uint8_t** out) {
+  SFMX_REQUIRE(c, c && p && out);
+  *out = nullptr;
+  if (p->fetched_level != level || !p->ready) return SFMX_OK;  // not fetched: the caller downloads
+  SFMX_HIP(c, hipEventSynchronize(p->ready));
+  *out = p->fetched.as<uint8_t>();
+  return SFMX_OK;
 }
 
 int sfmx_pyramid_download_level(sfmx_ctx* c, const sfmx_pyramid* p, int level, uint8_t* host_out) {
   SFMX_REQUIRE(c, c && p && host_out && level >= 0 && level < p->levels);
+  if (int rc = sfmx_pyramid_settle(c, p)) return rc;
   const size_t nb = (size_t)p->lw[level] * p->lh[level];
   if (nb == 0) return SFMX_OK;
   SFMX_HIP(c, hipMemcpyAsync(host_out, p->base + p->off[level], nb, hipMemcpyDeviceToHost, c->stream));
@@ -762,6 +813,7 @@ __global__ void k_flag_row_write(const double* __restrict__ score, const uint8_t
 }
 
 static int launch_score(sfmx_ctx* c, const sfmx_pyramid* p, double* d_score, unsigned long long* d_max) {
+  if (int rc = sfmx_pyramid_settle(c, p)) return rc;
   SFMX_HIP(c, hipMemsetAsync(d_max, 0, 8, c->stream));
   dim3 b(ST_TX, ST_TY), g((p->w + ST_TX - 1) / ST_TX, (p->h + ST_TY - 1) / ST_TY);
   KernelTimer t(c);
@@ -886,19 +938,25 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   if (rc) return rc;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   prof_begin(c, KID_SHI_FIXPOINT);  // init + dense sweeps + work-list sweeps + tail + compaction
-  // SFMX_SHI_MODE=tile[,passes[,rounds]]: the tile-resident fixpoint (k_shi_tile) instead of the sweep schedule below
-  static int tile_passes = 0, tile_rounds = 64;
+  // Schedule of the fixpoint: the tile-resident kernel (k_shi_tile) for images of a megapixel or more -- there the corner
+  // detection bounds the tracker lane and the tile schedule needs less than half the device time -- and the sweep schedule below
+  // for smaller ones, where the tile kernel's large resident workgroups cost the neighbouring lanes more than they save
+  // (DESIGN.md 4.2).  SFMX_SHI_MODE=tile[,passes[,rounds]] | sweeps overrides; any schedule is exact.
+  static int mode_passes = -1, tile_rounds = 64;  // -1: by image size
   static const bool tile_parsed = [] {
     if (const char* e = getenv("SFMX_SHI_MODE")) {
       int a = 3, b = 64;
       if (strncmp(e, "tile", 4) == 0) {
-        tile_passes = 3;
-        if (sscanf(e, "tile,%d,%d", &a, &b) >= 1) { tile_passes = a < 1 ? 1 : (a > 16 ? 16 : a); tile_rounds = b < 1 ? 1 : b; }
+        mode_passes = 3;
+        if (sscanf(e, "tile,%d,%d", &a, &b) >= 1) { mode_passes = a < 1 ? 1 : (a > 16 ? 16 : a); tile_rounds = b < 1 ? 1 : b; }
+      } else if (strncmp(e, "sweeps", 6) == 0) {
+        mode_passes = 0;
       }
     }
     return true;
   }();
   (void)tile_parsed;
+  const int tile_passes = mode_passes >= 0 ? mode_passes : ((size_t)p->w * p->h >= (size_t)1000000 ? 3 : 0);
   if (tile_passes > 0) {
     const size_t lds = shi_tile_lds(min_dist, c->wl_ntaps);
     for (int pass = 0; pass < tile_passes; ++pass) {

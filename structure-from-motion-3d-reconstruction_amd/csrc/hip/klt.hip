@@ -192,7 +192,7 @@ __device__ __forceinline__ double lerp_lds(const float* __restrict__ win, const 
 // STAMP: diagnostic build (SFMX_KLT_STAMPS=1) that accumulates s_memtime deltas per phase of the step loop for track 0
 // into stamps[0..7] (a buffer nothing else reads); the production instantiation has no stamp code.
 template <int r, bool STAMP>
-__global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
                                                   int iters, double fb_thresh, double* __restrict__ xy_fwd,
                                                   double* __restrict__ xy_back, uint8_t* __restrict__ keep,
                                                   unsigned long long* __restrict__ step_counter, unsigned long long* __restrict__ stamps,
@@ -840,6 +840,8 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   SFMX_REQUIRE(c, pa->w == pb->w && pa->h == pb->h && pa->levels == pb->levels);
   SFMX_REQUIRE(c, cfg->levels >= 1 && cfg->levels <= pa->levels && cfg->win_radius >= 1 && cfg->win_radius <= KLT_MAX_R && cfg->iters >= 0);
   if (n_steps_out) *n_steps_out = 0;
+  if (int rc = sfmx_pyramid_settle(c, pa)) return rc;
+  if (int rc = sfmx_pyramid_settle(c, pb)) return rc;
   if (n == 0) return SFMX_OK;
   SFMX_REQUIRE(c, xy_in != nullptr);
   const size_t nb = (size_t)n * 16;

@@ -115,6 +115,11 @@ struct sfmx_pyramid {
   size_t off[SFMX_MAX_LEVELS] = {0};
   int lw[SFMX_MAX_LEVELS] = {0}, lh[SFMX_MAX_LEVELS] = {0};
   size_t bytes = 0;
+  // sfmx_pyramid_set_device_async: built on the context's second stream; `ready` orders later users behind it
+  hipEvent_t ready = nullptr;
+  bool ready_pending = false;
+  int fetched_level = -1;     // level whose pixels were copied to `fetched` (pinned host memory) by the same call
+  PinBuf fetched;
 };
 
 // by-value kernel argument describing one pyramid
@@ -136,6 +141,7 @@ static inline PyrDesc make_desc(const sfmx_pyramid* p) {
 }
 
 int sfmx_fail(sfmx_ctx* ctx, int status, const char* what, hipError_t e);
+int sfmx_pyramid_settle(sfmx_ctx* ctx, const sfmx_pyramid* pyr);  // image.hip: order the main stream behind an asynchronous build
 extern "C" void sfmx_release_graphs(sfmx_ctx* ctx);  // image.hip: drop the hipGraph executables cached for this context
 
 #define SFMX_HIP(ctx, call)                                                         \

@@ -34,6 +34,12 @@ void MemoryFrames::load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) {
   else check(ctx, sfmx_pyramid_upload(ctx, pyr, host + off), "pyramid_upload");
 }
 
+bool MemoryFrames::load_async(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr, int fetch_level) {
+  if (!dev || fi < 0 || fi >= n) return false;
+  check(ctx, sfmx_pyramid_set_device_async(ctx, pyr, dev + (size_t)fi * (size_t)w * (size_t)h, fetch_level), "pyramid_set_device_async");
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------ tracker
 GpuTracker::GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk, int ring, std::function<void(int)> before_load,
                        const std::vector<sfmx_pyramid*>* borrowed)
@@ -529,9 +535,12 @@ void CornerPrefetcher::run_resolver(Worker& w) {
 
 void GpuTracker::reset(FrameSource& src, int fi) {
   const int next = have_prev_ ? (slot_ + 1) % (int)ring_.size() : slot_;
-  if (before_load_) before_load_(fi);
   const auto t0 = Clock::now();
-  src.load(ctx_, fi, ring_[(size_t)next]);
+  if (!(preloaded_frame_ == fi && preloaded_slot_ == next)) {
+    if (before_load_) before_load_(fi);
+    src.load(ctx_, fi, ring_[(size_t)next]);
+  }
+  preloaded_frame_ = -1;
   if (clk_) clk_->upload += since(t0);
   slot_ = next;
   have_prev_ = true;
@@ -564,11 +573,18 @@ StepOut GpuTracker::step(FrameSource& src, int fi) {
     return {};
   }
   const int next = (slot_ + 1) % (int)ring_.size();
-  if (before_load_) before_load_(fi);  // the slot's previous tenant must have been released by the geometry lane
-  auto t0 = Clock::now();
   sfmx_pyramid* prev = ring_[(size_t)slot_];
   sfmx_pyramid* cur = ring_[(size_t)next];
-  src.load(ctx_, fi, cur);  // pyr1; pyr0 is the cached pyramid of the previous frame (identical to rebuilding it, T:345)
+  const bool ahead = preloaded_frame_ == fi && preloaded_slot_ == next;  // built on the second stream; sfmx_klt_track orders itself behind it
+  if (!ahead && before_load_) before_load_(fi);  // the slot's previous tenant must have been released by the geometry lane
+  auto t0 = Clock::now();
+  if (!ahead) src.load(ctx_, fi, cur);  // pyr1; pyr0 is the cached pyramid of the previous frame (identical to rebuilding it, T:345)
+  preloaded_frame_ = -1;
+  // the next frame's pyramid, while this frame's KLT runs: into the slot after `cur`, if that slot is free already
+  if (may_load_ && ring_.size() >= 3 && fi + 1 < src.count() && may_load_(fi + 1)) {
+    const int after = (next + 1) % (int)ring_.size();
+    if (src.load_async(ctx_, fi + 1, ring_[(size_t)after], fetch_level_)) { preloaded_frame_ = fi + 1; preloaded_slot_ = after; }
+  }
   if (clk_) clk_->upload += since(t0);
   std::vector<V2> p0(tracks_.size()), fwd;
   std::vector<std::uint8_t> keep;
@@ -911,6 +927,15 @@ void GpuBundleAdjuster::solve(BaJob& job) {
   else check(ctx_, sfmx_ba_reset(ctx_, prob_, W, Pl, Xp, optr, oli, ouv), "ba_reset");
   std::vector<double> poses((size_t)W * 12), dx((size_t)D);
   if (clk_) clk_->ba_calls++;
+  const bool plain = !by_elements && !sharded && !virtual_world;
+  struct JobGuard {  // the resident kernel of a job never outlives the job, whatever ends it
+    sfmx_ctx* c; sfmx_ba_problem* q; bool on;
+    ~JobGuard() { if (on) (void)sfmx_ba_end(c, q); }
+  } job_guard{ctx_, prob_, false};
+  if (plain) {
+    check(ctx_, sfmx_ba_begin(ctx_, prob_, job.cfg.iters, K(0, 0), K(1, 1), K(0, 2), K(1, 2), job.cfg.huber_delta, job.cfg.lambda), "ba_begin");
+    job_guard.on = true;
+  }
   for (int it = 0; it < job.cfg.iters; ++it) {
     for (int li = 0; li < W; li++) {
       Mat3 R;
@@ -963,14 +988,33 @@ AsyncLane::~AsyncLane() {
   if (th_.joinable()) th_.join();
   ContextPool::instance().release(pc_);
 }
+// how long a thread polls for a hand-off before it sleeps (SFMX_SPIN_US, 0 = sleep at once)
+static std::chrono::microseconds spin_window() {
+  static const int us = std::getenv("SFMX_SPIN_US") ? std::max(0, std::atoi(std::getenv("SFMX_SPIN_US"))) : 300;
+  return std::chrono::microseconds(us);
+}
+template <class Pred>
+static bool spin_until(Pred&& ready) {
+  const auto win = spin_window();
+  if (win.count() == 0) return ready();
+  const auto t0 = Clock::now();
+  for (int i = 0;; ++i) {
+    if (ready()) return true;
+    __builtin_ia32_pause();
+    if ((i & 63) == 63 && Clock::now() - t0 > win) return false;
+  }
+}
 void AsyncLane::submit(std::function<void()> task) {
   {
     std::lock_guard<std::mutex> lk(mu_);
     queue_.push_back(std::move(task));
+    submitted_.fetch_add(1, std::memory_order_release);
   }
   cv_task_.notify_one();
 }
 void AsyncLane::wait() {
+  const std::uint64_t want = submitted_.load(std::memory_order_acquire);
+  (void)spin_until([&] { return completed_.load(std::memory_order_acquire) >= want; });
   std::unique_lock<std::mutex> lk(mu_);
   cv_idle_.wait(lk, [&] { return queue_.empty() && !busy_; });
   if (error_) {
@@ -981,8 +1025,10 @@ void AsyncLane::wait() {
 }
 void AsyncLane::run() {
   (void)sfmx_ctx_make_current(ctx_);
+  std::uint64_t taken = 0;
   for (;;) {
     std::function<void()> task;
+    (void)spin_until([&] { return submitted_.load(std::memory_order_acquire) > taken; });
     {
       std::unique_lock<std::mutex> lk(mu_);
       cv_task_.wait(lk, [&] { return stop_ || !queue_.empty(); });
@@ -990,6 +1036,7 @@ void AsyncLane::run() {
       task = std::move(queue_.front());
       queue_.pop_front();
       busy_ = true;
+      ++taken;
     }
     const auto tb = Clock::now();
     try {
@@ -1002,6 +1049,7 @@ void AsyncLane::run() {
       std::lock_guard<std::mutex> lk(mu_);
       busy_seconds_ += since(tb);
       busy_ = false;
+      completed_.fetch_add(1, std::memory_order_release);
     }
     cv_idle_.notify_all();
   }
@@ -1104,7 +1152,10 @@ std::vector<float> global_desc_32(sfmx_ctx* ctx, sfmx_pyramid* pyr, int level) {
   int dw = 0, dh = 0;
   sfmx_pyramid_level_size(pyr, level, &dw, &dh);
   std::vector<std::uint8_t> d((size_t)std::max(1, dw * dh));
-  check(ctx, sfmx_pyramid_download_level(ctx, pyr, level, d.data()), "pyramid_download_level");
+  const std::uint8_t* fetched = nullptr;  // the level came to the host with an asynchronous build of this pyramid?
+  check(ctx, sfmx_pyramid_fetched_level(ctx, pyr, level, &fetched), "pyramid_fetched_level");
+  if (fetched) std::memcpy(d.data(), fetched, (size_t)dw * dh);
+  else check(ctx, sfmx_pyramid_download_level(ctx, pyr, level, d.data()), "pyramid_download_level");
   std::vector<float> v;
   v.reserve(1024);
   double mean = 0.0;
@@ -1171,6 +1222,7 @@ FrameFeeder::FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig&
     std::function<void(int)> hook;
     if (threaded)
       hook = [this](int fi) {  // frame fi is about to overwrite the pyramid of frame fi - ring
+        (void)spin_until([&] { return released_a_.load(std::memory_order_acquire) >= fi - ring_; });
         std::unique_lock<std::mutex> lk(mu_);
         cv_rel_.wait(lk, [&] { return stop_ || released_ >= fi - ring_; });
         if (stop_) throw SfmxFailure(SFMX_ERR_INVALID, "tracker lane stopped");
@@ -1179,6 +1231,11 @@ FrameFeeder::FrameFeeder(sfmx_ctx* caller_ctx, FrameSource& src, const LKConfig&
     if (pc_) borrowed = &pc_->pyramid_ring(src.width(), src.height(), std::max(cfg.pyr_levels, extra_levels), ring_);
     tracker_ = std::make_unique<GpuTracker>(ctx_, cfg, src.width(), src.height(), extra_levels, clk_, ring_, hook, borrowed);
     tracker_->set_prefetcher(prefetch_);
+    if (threaded && !std::getenv("SFMX_NO_PRELOAD"))
+      tracker_->enable_preload([this](int fi) {
+        std::lock_guard<std::mutex> lk(mu_);
+        return !stop_ && released_ >= fi - ring_;
+      }, desc_level_);
     if (prefetch_)  // the corners of the first frames are on their way before the tracker asks for them (T:330 at frame 0)
       for (int a = 0; a <= prefetch_depth_ && a < n_frames_; ++a) prefetch_->request(a);
     if (threaded) th_ = std::thread([this] { run(); });
@@ -1236,6 +1293,7 @@ void FrameFeeder::run() {
       {
         std::lock_guard<std::mutex> lk(mu_);
         queue_.push_back(std::move(p));
+        produced_.fetch_add(1, std::memory_order_release);
       }
       cv_pkt_.notify_one();
     }
@@ -1251,6 +1309,7 @@ void FrameFeeder::run() {
 }
 FramePacket FrameFeeder::next() {
   if (!pc_) return produce(next_frame_++);
+  (void)spin_until([&] { return produced_.load(std::memory_order_acquire) > consumed_; });
   std::unique_lock<std::mutex> lk(mu_);
   cv_pkt_.wait(lk, [&] { return !queue_.empty() || done_; });
   if (queue_.empty()) {
@@ -1259,6 +1318,7 @@ FramePacket FrameFeeder::next() {
   }
   FramePacket p = std::move(queue_.front());
   queue_.pop_front();
+  ++consumed_;
   return p;
 }
 void FrameFeeder::finish() {
@@ -1269,6 +1329,7 @@ void FrameFeeder::release_upto(int frame) {
     std::lock_guard<std::mutex> lk(mu_);
     if (frame <= released_) return;
     released_ = frame;
+    released_a_.store(frame, std::memory_order_release);
   }
   cv_rel_.notify_all();
 }
@@ -1324,11 +1385,15 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   // it starts as soon as the tracker lane has produced the packet, on a context of its own; the geometry lane picks the result
   // up with the packet (SFMX_NO_RANSAC_LANE=1: computed by the geometry lane itself, as before).
   PhaseMark pm_lane_a{"~lane_a.. done", t_all};
-  StageClock lane_a_clk;
-  std::unique_ptr<AsyncLane> lane_a;
-  if (track_lane && !std::getenv("SFMX_NO_RANSAC_LANE"))
+  StageClock lane_a_clk, lane_a2_clk;  // declared before the lanes: their tasks may still run while the lanes are torn down
+  std::unique_ptr<AsyncLane> lane_a, lane_a2;  // lane_a2 (SFMX_RANSAC_LANES=2): odd frames, so that a call has two frame times
+  if (track_lane && !std::getenv("SFMX_NO_RANSAC_LANE")) {
     lane_a = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A);
+    if (const char* e = std::getenv("SFMX_RANSAC_LANES"))
+      if (std::atoi(e) >= 2) lane_a2 = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A2);
+  }
   if (lane_a && sfmx_get_timing(ctx)) (void)sfmx_set_timing(lane_a->ctx(), 1);
+  if (lane_a2 && sfmx_get_timing(ctx)) (void)sfmx_set_timing(lane_a2->ctx(), 1);
   // multi-GPU run: a lane computes this rank's half of a RANSAC call (ransac_local), the geometry thread merges it with the
   // other ranks' where it consumes the result -- the one place whose order is the same on every rank
   sfmx_comm* const rcomm = cfg.comm_ransac;
@@ -1351,14 +1416,15 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   };
   std::function<void(FramePacket&)> on_packet;
   if (lane_a)
-    on_packet = [&lane_a, &lane_a_clk, K, ransac_ahead](FramePacket& p) {
+    on_packet = [&lane_a, &lane_a2, &lane_a_clk, &lane_a2_clk, K, ransac_ahead](FramePacket& p) {
       if (p.step.prev_pts.empty()) return;
       auto prom = std::make_shared<std::promise<std::shared_ptr<RansacAhead>>>();
       p.rel = prom->get_future().share();
       auto pi = std::make_shared<const std::vector<V2>>(p.step.prev_pts);
       auto pj = std::make_shared<const std::vector<V2>>(p.step.cur_pts);
-      AsyncLane* la = lane_a.get();
-      StageClock* ck = &lane_a_clk;
+      const bool second = lane_a2 && (p.fi & 1);
+      AsyncLane* la = second ? lane_a2.get() : lane_a.get();
+      StageClock* ck = second ? &lane_a2_clk : &lane_a_clk;
       la->submit([prom, pi, pj, la, ck, K, ransac_ahead]() {
         try {
           prom->set_value(ransac_ahead(la->ctx(), K, *pi, *pj, 2500, 1e-3, 60, ck));
@@ -1737,9 +1803,14 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   phase("lanes joined");
   feeder.finish();
   phase("feeder finished");
+  if (lane_a2) {
+    lane_a2->wait();
+    lane_a_clk.add(lane_a2_clk);
+    if (sfmx_get_timing(ctx)) clk.grab_profile(lane_a2->ctx());
+  }
   if (lane_a) {
     lane_a->wait();
-    clk.lane_a_busy = lane_a->busy_seconds();
+    clk.lane_a_busy = std::max(lane_a->busy_seconds(), lane_a2 ? lane_a2->busy_seconds() : 0.0);
     clk.ransac += lane_a_clk.ransac; clk.ransac_kernel_us += lane_a_clk.ransac_kernel_us; clk.ransac_calls += lane_a_clk.ransac_calls;
     clk.ransac_points += lane_a_clk.ransac_points; clk.ransac_verified += lane_a_clk.ransac_verified;
     clk.ransac_cert_misses += lane_a_clk.ransac_cert_misses;

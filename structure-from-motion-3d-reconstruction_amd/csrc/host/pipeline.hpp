@@ -4,6 +4,7 @@
 // Nothing here falls back to CPU arithmetic for the hot kernels: a failing C-ABI call is an error.
 #pragma once
 #include <array>
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -55,6 +56,9 @@ struct FrameSource {
   virtual int height() const = 0;
   // loads frame fi into pyr (level 0 + downsampled levels); throws std::runtime_error like read_pgm
   virtual void load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) = 0;
+  // the same ahead of time on the context's second stream (sfmx_pyramid_set_device_async), if the source can: false = not
+  // started, the caller loads the frame when it needs it.  fetch_level >= 0: that level's pixels also travel to the host.
+  virtual bool load_async(sfmx_ctx*, int, sfmx_pyramid*, int /*fetch_level*/) { return false; }
 };
 struct MemoryFrames : FrameSource {
   const std::uint8_t* host = nullptr;  // [n][h][w]
@@ -64,6 +68,7 @@ struct MemoryFrames : FrameSource {
   int width() const override { return w; }
   int height() const override { return h; }
   void load(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr) override;
+  bool load_async(sfmx_ctx* ctx, int fi, sfmx_pyramid* pyr, int fetch_level) override;
 };
 
 struct StageClock {
@@ -108,7 +113,7 @@ struct PooledCtx {
 class ContextPool {
  public:
   static ContextPool& instance();
-  enum Role { PREFETCH = 1, TRACKER = 2, LANE_B = 3, LANE_C = 4, LANE_A = 5, LANE_E = 6 };
+  enum Role { PREFETCH = 1, TRACKER = 2, LANE_B = 3, LANE_C = 4, LANE_A = 5, LANE_E = 6, LANE_A2 = 7 };
   PooledCtx* acquire(int device, int priority, int role);
   void release(PooledCtx* pc);  // synchronises the context; the caller's threads must have stopped using it
   void clear();
@@ -226,6 +231,10 @@ class GpuTracker {
   // borrowed: pyramids owned by somebody else (a pooled context); otherwise `ring` pyramids are created and owned here
   GpuTracker(sfmx_ctx* ctx, LKConfig cfg, int w, int h, int extra_levels, StageClock* clk, int ring = 2,
              std::function<void(int)> before_load = nullptr, const std::vector<sfmx_pyramid*>* borrowed = nullptr);
+  // Preloading: while the KLT launch of frame fi runs, the pyramid of frame fi + 1 is built on the context's second stream
+  // (and the pixels of `fetch_level`, the descriptor's source, copied to the host).  may_load(f) must say -- without
+  // blocking -- whether the ring slot of frame f is free already.
+  void enable_preload(std::function<bool(int)> may_load, int fetch_level) { may_load_ = std::move(may_load); fetch_level_ = fetch_level; }
   ~GpuTracker();
   GpuTracker(const GpuTracker&) = delete;
   GpuTracker& operator=(const GpuTracker&) = delete;
@@ -250,6 +259,8 @@ class GpuTracker {
   bool owns_ring_ = true;
   int slot_ = 0;
   std::function<void(int)> before_load_;
+  std::function<bool(int)> may_load_;
+  int fetch_level_ = -1, preloaded_frame_ = -1, preloaded_slot_ = -1;
   bool have_prev_ = false;
   std::vector<Track> tracks_;
   std::vector<int> grid_head_, grid_next_;  // scratch of the replenish distance filter
@@ -336,6 +347,9 @@ class FrameFeeder {
   std::condition_variable cv_pkt_, cv_rel_;
   std::deque<FramePacket> queue_;
   int released_ = -1;
+  std::atomic<int> released_a_{-1};           // copies for the short polls that precede the sleeps on the condition variables
+  std::atomic<std::uint64_t> produced_{0};
+  std::uint64_t consumed_ = 0;
   bool stop_ = false, done_ = false;
   std::exception_ptr error_;
 };
@@ -449,6 +463,9 @@ class AsyncLane {
   std::condition_variable cv_task_, cv_idle_;
   std::deque<std::function<void()>> queue_;
   bool busy_ = false, stop_ = false;
+  // hand-offs of a few hundred microseconds apart: both sides poll these for a short while before they sleep on the condition
+  // variables (a futex wake-up costs 30-60 us per direction, twice per BA job and RANSAC call)
+  std::atomic<std::uint64_t> submitted_{0}, completed_{0};
   std::exception_ptr error_;
 };
 

@@ -112,6 +112,13 @@ int sfmx_pyramid_upload(sfmx_ctx* c, sfmx_pyramid* p, const uint8_t* host) {
   return SFMX_OK;
 }
 int sfmx_pyramid_set_device(sfmx_ctx* c, sfmx_pyramid* p, const void* dev) { return sfmx_pyramid_upload(c, p, static_cast<const uint8_t*>(dev)); }
+int sfmx_pyramid_set_device_async(sfmx_ctx* c, sfmx_pyramid* p, const void* dev, int) { return sfmx_pyramid_upload(c, p, static_cast<const uint8_t*>(dev)); }
+int sfmx_pyramid_wait(sfmx_ctx* c, sfmx_pyramid* p) { return (c && p) ? SFMX_OK : SFMX_ERR_INVALID; }
+int sfmx_pyramid_fetched_level(sfmx_ctx* c, sfmx_pyramid* p, int, const uint8_t** out) {
+  if (!c || !p || !out) return SFMX_ERR_INVALID;
+  *out = nullptr;  // nothing is fetched ahead of time here: the caller downloads
+  return SFMX_OK;
+}
 int sfmx_pyramid_download_level(sfmx_ctx* c, const sfmx_pyramid* p, int level, uint8_t* out) {
   if (!c || !p || !out || level < 0 || level >= p->levels) return fail(c, SFMX_ERR_INVALID, "pyramid_download_level");
   std::memcpy(out, p->px[(size_t)level].data(), (size_t)p->lw[(size_t)level] * p->lh[(size_t)level]);
@@ -242,6 +249,8 @@ static int ba_solve(sfmx_ctx* c, int D, std::vector<double>& S, std::vector<doub
   (void)c;
   return orc_solve_gauss(S.data(), b.data(), D, dx) ? SFMX_ERR_SINGULAR : SFMX_OK;
 }
+int sfmx_ba_begin(sfmx_ctx* c, sfmx_ba_problem* q, int, double, double, double, double, double, double) { return (c && q) ? SFMX_OK : SFMX_ERR_INVALID; }
+int sfmx_ba_end(sfmx_ctx* c, sfmx_ba_problem* q) { return (c && q) ? SFMX_OK : SFMX_ERR_INVALID; }
 int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses, double fx, double fy, double cx, double cy, double huber, double lambda,
                  double* dx) {
   if (!c || !q || !poses || !dx) return fail(c, SFMX_ERR_INVALID, "ba_step");

@@ -664,6 +664,43 @@ def test_ba_step_host_solve_equals_device_solve(ctx, shape, monkeypatch):
     prob.close()
 
 
+@pytest.mark.parametrize("P", [600, 37, 3])
+def test_ba_resident_job_equals_plain_steps(ctx, P, monkeypatch):
+    """sfmx_ba_begin / sfmx_ba_step x n / sfmx_ba_end: the resident kernel of a job (one launch, iterations driven through a
+    command word in pinned memory) must return, step for step, the dx of the plain two-launches-per-step path -- on a chain of
+    iterations whose poses depend on the previous dx, on a job that is ended early, and on a job that is longer than the
+    kernel was started for (the surplus steps take the plain path)."""
+    W = 6
+    pw, K, X, ptr, li, uv = _c4_like_problem(W, P, 31)
+    a = (K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    prob = ctx.ba_problem(W, X, ptr, li, uv)
+
+    def chain(n, resident, iters=None, end_after=None):
+        poses = pw.copy()
+        out = []
+        if resident:
+            prob.begin(iters if iters is not None else n, *a)
+        for k in range(n):
+            if end_after is not None and k == end_after:
+                prob.end()
+            rc, dx = prob.step(poses, *a)
+            assert rc == 0
+            out.append(dx.copy())
+            poses[1:, 9:] += 1e-3 * dx.reshape(W, 6)[1:, 3:]  # feed the step back (any deterministic function of dx)
+        if resident:
+            prob.end()
+        return out
+
+    monkeypatch.setenv("SFMX_BA_RESIDENT", "0")
+    ref = chain(5, False)
+    monkeypatch.setenv("SFMX_BA_RESIDENT", "1")  # opt-in: measured slower inside the pipeline (DESIGN.md 4.4)
+    for tag, got in (("5 of 5", chain(5, True)), ("ended after 2", chain(5, True, end_after=2)), ("7 steps on a 5-iteration job", chain(5, True, iters=3)),
+                     ("again", chain(5, True))):
+        for k in range(5):
+            H.assert_bits_equal(got[k], ref[k], f"resident job ({tag}) step {k}")
+    prob.close()
+
+
 def test_ba_sharded_step_single_rank_equals_fused_step(ctx):
     """sfmx_ba_step_sharded (partial build -> [all-reduce] -> damp/gauge kernel -> solve) with one rank must equal the fused
     sfmx_ba_step bit for bit: same sums, no collective reordering with world size 1 -- with no communicator and with a
