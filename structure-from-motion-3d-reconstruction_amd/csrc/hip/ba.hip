@@ -977,7 +977,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int W, int P, int MS, const double* poses_host, const double* __restrict__ X, const int32_t* __restrict__ obs_ptr,
     const int32_t* __restrict__ obs_li, const double* __restrict__ obs_uv, double fx, double fy, double cx, double cy, double huber,
     double lambda, double* __restrict__ rec, int8_t* __restrict__ slot_of, double* __restrict__ C, double* __restrict__ S,
-    double* __restrict__ b, BaResidentCtl* ctl, const unsigned long long* cmd_host, double* result_host, unsigned long long first_seq, int max_iters, int wave_prio) {
+    double* __restrict__ b, BaResidentCtl* ctl, const unsigned long long* cmd_host, double* result_host, unsigned long long first_seq, int max_iters,
+    int wave_prio, int n_elem_blocks) {
+  // n_elem_blocks <= gridDim.x: the first n_elem_blocks workgroups reduce one block of 16 elements each; all of them take part in
+  // the points phase and in the barriers
   __shared__ unsigned long long s_cmd;
   __shared__ int s_flag;
   __shared__ double s_poses[BA_MAX_W * 12];
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (!s_flag) return;
     __threadfence();
     // ---- reduction of this workgroup's element block over all points (damping and gauge included, T:1064-1071)
-    ba_reduce_body<64, 0, 2, 2>(W, P, C, lambda, 1, S, b, nullptr, nullptr, nullptr, 0, wave_prio, nullptr, blk, nblk, 0);
+    if (blk < n_elem_blocks) ba_reduce_body<64, 0, 2, 2>(W, P, C, lambda, 1, S, b, nullptr, nullptr, nullptr, 0, wave_prio, nullptr, blk, n_elem_blocks, 0);
     // ---- the last workgroup to finish hands S | b to the host
     __threadfence();
     __syncthreads();
@@ -1729,7 +1732,7 @@ int sfmx_ba_begin(sfmx_ctx* c, sfmx_ba_problem* q, int iters, double fx, double 
   k_ba_window_resident<<<ba_element_blocks(q), 256, 0, c->stream>>>(q->W, q->P, q->MS, c->h[0].as<double>(), q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy,
                                                                    cx, cy, huber, lambda, q->rec, q->slot_of, q->contrib, q->S, q->b,
                                                                    q->job_ctl.as<BaResidentCtl>(), q->job_cmd.as<unsigned long long>() + q->job_slot,
-                                                                   c->h[1].as<double>(), q->job_first_seq, iters, ba_wave_prio());
+                                                                   c->h[1].as<double>(), q->job_first_seq, iters, ba_wave_prio(), ba_element_blocks(q));
   SFMX_HIP(c, hipGetLastError());
   q->job_active = true;
   c->ba_upload_in_flight = false;  // the kernel is ordered behind the upload on the stream; nothing else touches the staging slab

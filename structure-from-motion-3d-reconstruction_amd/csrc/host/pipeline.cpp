@@ -988,9 +988,11 @@ AsyncLane::~AsyncLane() {
   if (th_.joinable()) th_.join();
   ContextPool::instance().release(pc_);
 }
-// how long a thread polls for a hand-off before it sleeps (SFMX_SPIN_US, 0 = sleep at once)
+// how long a thread polls for a hand-off before it sleeps (SFMX_SPIN_US; 0 = sleep at once)
 static std::chrono::microseconds spin_window() {
-  static const int us = std::getenv("SFMX_SPIN_US") ? std::max(0, std::atoi(std::getenv("SFMX_SPIN_US"))) : 300;
+  // default 0: measured on the 16-core share of a GPU box, polling threads take the cores the other lanes need
+  // (300 us: 1 358 / 1 361 keyframes/s against 1 456 / 1 403 without, profiles/r03_ab_spin.txt)
+  static const int us = std::getenv("SFMX_SPIN_US") ? std::max(0, std::atoi(std::getenv("SFMX_SPIN_US"))) : 0;
   return std::chrono::microseconds(us);
 }
 template <class Pred>

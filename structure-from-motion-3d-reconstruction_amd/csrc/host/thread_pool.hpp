@@ -48,7 +48,6 @@ class WorkerTeam {
       next_.store(0);
       tickets_ = need;
       pending_ = need;
-      epoch_.fetch_add(1, std::memory_order_release);
     }
     if (need == (int)workers_.size()) cv_.notify_all();
     else for (int i = 0; i < need; i++) cv_.notify_one();
@@ -68,18 +67,7 @@ class WorkerTeam {
     }
   }
   void worker() {
-    std::uint64_t seen = 0;
     for (;;) {
-      // regions come in bursts (a keyframe block starts three within a few hundred microseconds): poll for the next one for a
-      // short while before sleeping -- a futex wake-up costs as much as a whole region of 2-5 us solves
-      {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; epoch_.load(std::memory_order_acquire) == seen; ++i) {
-          __builtin_ia32_pause();
-          if ((i & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
-        }
-        seen = epoch_.load(std::memory_order_acquire);
-      }
       {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return stop_ || tickets_ > 0; });  // a ticket = the right to join the current region
@@ -99,7 +87,6 @@ class WorkerTeam {
   const std::function<void(int)>* fn_ = nullptr;
   int n_ = 0, grain_ = 16, pending_ = 0, tickets_ = 0;
   std::atomic<int> next_{0};
-  std::atomic<std::uint64_t> epoch_{0};
   bool stop_ = false;
 };
 

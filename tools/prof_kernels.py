@@ -31,4 +31,11 @@ for _ in range(5):
     prob.step(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
 print("ba W 6 P 600")
 prob.close()
+if os.environ.get("SFMX_PROF_C4"):  # BASELINE config C4: W = 10, P = 50 000 (what the chunked row ring moves per iteration)
+    pw, K, X, ptr, li, uv = I.ba_problem(10, 50000)
+    prob = ctx.ba_problem(10, X, ptr, li, uv)
+    for _ in range(3):
+        prob.step_sharded_elements(None, pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
+    print("ba W 10 P 50000")
+    prob.close()
 ctx.close()

@@ -15,6 +15,7 @@ echo "bench line done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_trace" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --batched-probe 0 > "$OUT/bench_trace.log" 2>&1
 echo "bench trace done"
 export SFMX_PROF_META="$PWD/profiles/${TAG}_pmc_meta.json"
+export SFMX_PROF_C4=1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pmc/trace" -- python3 tools/prof_kernels.py > "$OUT/pmc_trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc/fetch" -- python3 tools/prof_kernels.py > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc/write" -- python3 tools/prof_kernels.py > "$OUT/pmc_write.log" 2>&1
@@ -23,10 +24,14 @@ echo "pmc passes done"
 python tools/summarize_profiles.py "$TAG" "$OUT/bench_trace" "$OUT/pmc"
 python tools/microbench.py > "profiles/${TAG}_microbench.txt" 2>&1
 echo "microbench done"
-python tools/bench_c3.py --frames 100 > "profiles/${TAG}_c3_prefix_line.json" 2> "$OUT/c3.err"
+python tools/bench_c3.py --frames ${C3_FRAMES:-1000} --passes ${C3_PASSES:-2} > "profiles/${TAG}_c3_line.json" 2> "$OUT/c3.err"
+echo "c3 done"
+python tools/bench_c5.py --frames ${C5_FRAMES:-60} > "profiles/${TAG}_c5_prefix_line.json" 2> "$OUT/c5.err"
+echo "c5 done"
 python bench.py --mode ba-sharded --steps 10 --warmup 2 > "profiles/${TAG}_ba_sharded_1gpu_line.json" 2> "$OUT/ba_sharded.err"
 python tools/posegraph_c5.py > "profiles/${TAG}_posegraph_c5.txt" 2> "$OUT/pg.err"
 python tools/ransac_cond_probe.py > "profiles/${TAG}_ransac_cond_probe.txt" 2> "$OUT/cond.err"
+python tools/virtual_world_probe.py > "profiles/${TAG}_virtual_world.jsonl" 2> "$OUT/vw.err"
 SFMX_KLT_STAMPS=1 python tools/klt_stamps.py 2>&1 | grep -v amdgpu.ids > "profiles/${TAG}_klt_stamps.txt"
 echo "extras done"
 mkdir -p "gpurun_out/profiles_$TAG" && cp profiles/${TAG}_* "gpurun_out/profiles_$TAG/"
