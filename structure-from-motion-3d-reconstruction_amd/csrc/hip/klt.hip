@@ -192,7 +192,7 @@ __device__ __forceinline__ double lerp_lds(const float* __restrict__ win, const 
 // STAMP: diagnostic build (SFMX_KLT_STAMPS=1) that accumulates s_memtime deltas per phase of the step loop for track 0
 // into stamps[0..7] (a buffer nothing else reads); the production instantiation has no stamp code.
 template <int r, bool STAMP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
+__global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
                                                   int iters, double fb_thresh, double* __restrict__ xy_fwd,
                                                   double* __restrict__ xy_back, uint8_t* __restrict__ keep,
                                                   unsigned long long* __restrict__ step_counter, unsigned long long* __restrict__ stamps,

@@ -1373,8 +1373,11 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       for (PooledCtx* pc : made) ContextPool::instance().release(pc);
     }
   }
-  int prefetch_workers = 2;  // one worker's 0.9 ms per frame was the tracker lane's bound (it waited 26 of 52 ms for corners)
-  if (const char* e = std::getenv("SFMX_PREFETCH_WORKERS")) prefetch_workers = std::min(4, std::max(1, std::atoi(e)));
+  // one worker's 0.9 ms per frame was the tracker lane's bound at 640x480 (it waited 26 of 52 ms for corners): two there.  At
+  // 1920x1080 a frame has ~600 k candidates and the tie-order replay on the worker's resolver thread takes milliseconds: with two
+  // workers the tracker waited 0.37 s of a 0.41 s pass for corners (C5 prefix, 141 frames/s), with four 0.19 of 0.25 s (248 frames/s)
+  int prefetch_workers = (size_t)w * (size_t)h >= (size_t)1000000 ? 6 : 2;
+  if (const char* e = std::getenv("SFMX_PREFETCH_WORKERS")) prefetch_workers = std::min(8, std::max(1, std::atoi(e)));
   PhaseMark pm_prefetch{"~prefetch.. done", t_all};
   std::unique_ptr<CornerPrefetcher> prefetch;
   if (!std::getenv("SFMX_NO_PREFETCH") && std::min(cfg.frames, src.count()) > 1 && cfg.klt.min_distance >= 1 && cfg.klt.min_distance <= 16) {
@@ -1391,8 +1394,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   std::unique_ptr<AsyncLane> lane_a, lane_a2;  // lane_a2 (SFMX_RANSAC_LANES=2): odd frames, so that a call has two frame times
   if (track_lane && !std::getenv("SFMX_NO_RANSAC_LANE")) {
     lane_a = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A);
-    if (const char* e = std::getenv("SFMX_RANSAC_LANES"))
-      if (std::atoi(e) >= 2) lane_a2 = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A2);
+    // a second lane for the odd frames when a call is expensive (its cost grows with the number of correspondences): with 5 000
+    // tracks per frame (C3) lane A was busy 1.23 s of a 2.2 s pass and the geometry thread waited for it -- 437 -> 543 frames/s with
+    // two lanes; at the reference's 2 200 tracks the second lane changes nothing (SFMX_RANSAC_LANES=1|2 overrides)
+    int ransac_lanes = cfg.klt.max_tracks > 3000 ? 2 : 1;
+    if (const char* e = std::getenv("SFMX_RANSAC_LANES")) ransac_lanes = std::atoi(e);
+    if (ransac_lanes >= 2) lane_a2 = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A2);
   }
   if (lane_a && sfmx_get_timing(ctx)) (void)sfmx_set_timing(lane_a->ctx(), 1);
   if (lane_a2 && sfmx_get_timing(ctx)) (void)sfmx_set_timing(lane_a2->ctx(), 1);

@@ -664,6 +664,23 @@ def test_ba_step_host_solve_equals_device_solve(ctx, shape, monkeypatch):
     prob.close()
 
 
+@pytest.mark.parametrize("shape", [(6, 600), (6, 17), (10, 300), (3, 33), (2, 4000)])
+def test_ba_build_window_shapes_equal_oracle(ctx, shape):
+    """sfmx_ba_build on window-sized problems of several shapes (2 to 10 poses, 17 to 4 000 points) against the oracle's build:
+    S and b bit for bit, with and without damping / gauge."""
+    W, P = shape
+    pw, K, X, ptr, li, uv = _c4_like_problem(W, P, 41)
+    prob = ctx.ba_problem(W, X, ptr, li, uv)
+    for damp in (True, False):
+        S, b = prob.build(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3, damp)
+        eS, eb = np.zeros((6 * W, 6 * W)), np.zeros(6 * W)
+        O.call("orc_ba_build", None, H.f64(pw), W, H.f64(X), P, H.i32(ptr), H.i32(li), H.f64(uv), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]),
+               float(K[1, 2]), 3.0, 1e-3, int(damp), eS, eb)
+        H.assert_bits_equal(S, eS, f"S W={W} P={P} damp={damp}")
+        H.assert_bits_equal(b, eb, f"b W={W} P={P} damp={damp}")
+    prob.close()
+
+
 @pytest.mark.parametrize("P", [600, 37, 3])
 def test_ba_resident_job_equals_plain_steps(ctx, P, monkeypatch):
     """sfmx_ba_begin / sfmx_ba_step x n / sfmx_ba_end: the resident kernel of a job (one launch, iterations driven through a

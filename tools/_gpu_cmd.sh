@@ -1,3 +1,4 @@
-SFMX_BA_ONE_LAUNCH=1 python -m pytest tests -m gpu -q -k "ba_build_and_step or host_solve or ba_edge or bench_workload" > gpurun_out/r03_j_tests.log 2>&1
-pr='import sys,json; d=json.loads(sys.stdin.read()); h=d["host_seconds_per_step"]; c=d["counters_per_step"]; print(d["value"], d["ms_per_step"], d["passes_bit_identical"], {k[4:]: round(h[k]*1e3,1) for k in ("sec_m_step","sec_m_kf","sec_join_wait","sec_lane_a_busy","sec_lane_b_busy","sec_lane_e_busy","sec_pf_busy")})'
-for env in "X=1" "SFMX_BA_ONE_LAUNCH=1" "X=2" "SFMX_BA_ONE_LAUNCH=1" "X=3" "SFMX_BA_ONE_LAUNCH=1"; do echo "== $env"; env $env timeout -k 10 120 python bench.py --no-cpu-baseline --batched-probe 0 --sharded-probe 0 --steps 15 | python -c "$pr"; done > gpurun_out/r03_j_ab.txt 2>&1
+for env in "X=1" "SFMX_PREFETCH_WORKERS=4" "SFMX_PREFETCH_WORKERS=8"; do echo "== C5 $env"; env $env python tools/bench_c5.py --frames 60 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['frames_per_s'], d['ms_per_frame'], d['passes_bit_identical'], d['host_seconds'])"; done > gpurun_out/r03_m_c5.txt 2>&1
+timeout -k 10 700 python -m pytest tests -m gpu -x -q > gpurun_out/r03_m_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03_m_tests.log
+C3_FRAMES=1000 C3_PASSES=2 C5_FRAMES=60 bash tools/profile_round.sh r03 > gpurun_out/r03_m_profile.log 2>&1; echo "profile rc=$?" >> gpurun_out/r03_m_profile.log
+SFMX_RANSAC_LANES=2 python tools/bench_c3.py --frames 1000 --passes 2 > gpurun_out/r03_m_c3_lanes2.json 2>/dev/null
