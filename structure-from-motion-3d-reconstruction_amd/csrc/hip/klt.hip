@@ -191,7 +191,9 @@ __device__ __forceinline__ double lerp_lds(const float* __restrict__ win, const 
 
 // STAMP: diagnostic build (SFMX_KLT_STAMPS=1) that accumulates s_memtime deltas per phase of the step loop for track 0
 // into stamps[0..7] (a buffer nothing else reads); the production instantiation has no stamp code.
-template <int r, bool STAMP>
+// PIPE (window radius 4 and 5: 64 < npix <= 128): the ordered sums over the first 64 pixels run UNDER the second half of the sample
+// grid and of the products -- see the PIPE branch below.  Same arithmetic, another instruction order.
+template <int r, bool STAMP, bool PIPE = false>
 __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
                                                   int iters, double fb_thresh, double* __restrict__ xy_fwd,
                                                   double* __restrict__ xy_back, uint8_t* __restrict__ keep,
@@ -229,17 +231,36 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
   static_assert(NCAN <= 32, "one descriptor lane per grid slot and axis");
   // the samples of this lane, fixed for the whole kernel.  Sample e < NCAN^2 is I1 at grid point (e / NCAN, e % NCAN), the
   // others are I0 at the centre points (slots 1..2r+1); a lane without a sample in the last round recomputes sample 0.
-  int samp_cd[L::SR], samp_rd[L::SR];
-  bool samp_i0[L::SR];
-  double* samp_out[L::SR];
-  const bool samp_ok_last = lane + 64 * (L::SR - 1) < L::NS;
+  // PIPE: the samples are ordered so that the first PR1 rounds hold everything the products of pixels 0..63 read (I1 rows
+  // 0..RH1 of the grid, I0 under those pixels) and the remaining PR2 rounds the rest
+  constexpr int RH1 = 63 / side + 2;                                                  // last I1 grid row pixels 0..63 touch
+  constexpr int PN1 = (RH1 + 1) * NCAN + 64, PR1 = (PN1 + 63) / 64;
+  constexpr int PN2 = (NCAN - RH1 - 1) * NCAN + (npix > 64 ? npix - 64 : 0), PR2 = (PN2 + 63) / 64;
+  constexpr int NSR = PIPE ? PR1 + PR2 : L::SR;                                       // sample rounds
+  int samp_cd[NSR], samp_rd[NSR];
+  bool samp_i0[NSR], samp_ok[NSR];
+  double* samp_out[NSR];
 #pragma unroll
-  for (int k = 0; k < L::SR; k++) {
-    int e = lane + 64 * k;
-    if (e >= L::NS) e = 0;
-    samp_i0[k] = e >= NCAN * NCAN;
-    samp_cd[k] = samp_i0[k] ? (e - NCAN * NCAN) % side + 1 : e % NCAN;
-    samp_rd[k] = samp_i0[k] ? (e - NCAN * NCAN) / side + 1 : e / NCAN;
+  for (int k = 0; k < NSR; k++) {
+    if constexpr (PIPE) {
+      const bool first = k < PR1;
+      const int idx = lane + 64 * (first ? k : k - PR1);
+      const int n_i1 = first ? (RH1 + 1) * NCAN : (NCAN - RH1 - 1) * NCAN;
+      const int n_all = first ? PN1 : PN2;
+      samp_ok[k] = idx < n_all;
+      const int id = samp_ok[k] ? idx : 0;
+      samp_i0[k] = id >= n_i1;
+      const int pix = (first ? 0 : 64) + (id - n_i1);                                  // I0: the pixel it lies under
+      samp_cd[k] = samp_i0[k] ? pix % side + 1 : id % NCAN;
+      samp_rd[k] = samp_i0[k] ? pix / side + 1 : (first ? 0 : RH1 + 1) + id / NCAN;
+    } else {
+      int e = lane + 64 * k;
+      samp_ok[k] = e < L::NS;
+      if (e >= L::NS) e = 0;
+      samp_i0[k] = e >= NCAN * NCAN;
+      samp_cd[k] = samp_i0[k] ? (e - NCAN * NCAN) % side + 1 : e % NCAN;
+      samp_rd[k] = samp_i0[k] ? (e - NCAN * NCAN) / side + 1 : e / NCAN;
+    }
     samp_out[k] = (samp_i0[k] ? G0 : G1) + samp_rd[k] * GS + samp_cd[k];
   }
   const double p0x = xy_in[2 * track], p0y = xy_in[2 * track + 1];
@@ -327,6 +348,108 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
           }
         }
         __syncthreads();
+        double acc = 0.0;
+        if constexpr (PIPE) {
+          static_assert(npix > 64 && npix <= 128, "two product rounds");
+          // the pieces of a step as callable blocks (everything is inlined; the indices are compile-time constants)
+          double2 fx[NSR], fy[NSR];
+          int po[NSR];
+          float pv[NSR][4];
+          auto taps_of = [&](int k) {
+            fx[k] = tapf[samp_cd[k]];
+            fy[k] = tapf[32 + samp_rd[k]];
+            po[k] = tapo[samp_cd[k]] + tapo[32 + samp_rd[k]];
+          };
+          auto pixels_of = [&](int k) {
+            const float* p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(samp_i0[k] ? win0 : win1) + po[k]);
+            pv[k][0] = p[0]; pv[k][1] = p[1]; pv[k][2] = p[KLT_PS]; pv[k][3] = p[KLT_PS + 1];
+          };
+          auto lerp_store = [&](int k) {
+            const double v0 = (double)pv[k][0] * fx[k].y + (double)pv[k][1] * fx[k].x;
+            const double v1 = (double)pv[k][2] * fx[k].y + (double)pv[k][3] * fx[k].x;
+            const double val = v0 * fy[k].y + v1 * fy[k].x;
+            if (samp_ok[k]) samp_out[k][0] = val;
+          };
+          const bool any_mis = (mis_p | mis_m) != 0ull;  // wave-uniform
+          if (any_mis) ++slow_steps;
+          double gxp, gxm, gyp, gym, gcc, irf;
+          auto product_reads = [&](int q) {
+            const int pix = lane + 64 * q < npix ? lane + 64 * q : 0;
+            const int i = pix / side, j = pix % side;
+            const double* gc1 = G1 + (i + 1) * GS + (j + 1);
+            gxp = gc1[1]; gxm = gc1[-1]; gyp = gc1[GS]; gym = gc1[-GS]; gcc = gc1[0];
+            irf = G0[(i + 1) * GS + (j + 1)];
+            if (any_mis) {
+              auto lerp = [&](const double2& fxx, const double2& fyy, int off) {
+                const float* p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(win1) + off);
+                const double v0 = (double)p[0] * fxx.y + (double)p[1] * fxx.x;
+                const double v1 = (double)p[KLT_PS] * fxx.y + (double)p[KLT_PS + 1] * fxx.x;
+                return v0 * fyy.y + v1 * fyy.x;
+              };
+              if ((mis_p >> j) & 1ull) gxp = lerp(xtapf[j], tapf[32 + i + 1], xtapo[j] + tapo[32 + i + 1]);
+              if ((mis_m >> j) & 1ull) gxm = lerp(xtapf[32 + j], tapf[32 + i + 1], xtapo[32 + j] + tapo[32 + i + 1]);
+              if ((mis_p >> (32 + i)) & 1ull) gyp = lerp(tapf[j + 1], xtapf[16 + i], tapo[j + 1] + xtapo[16 + i]);
+              if ((mis_m >> (32 + i)) & 1ull) gym = lerp(tapf[j + 1], xtapf[48 + i], tapo[j + 1] + xtapo[48 + i]);
+            }
+          };
+          auto product_stores = [&](int q) {
+            const int pix = lane + 64 * q;
+            if (pix < npix) {
+              const double Ix = 0.5 * (gxp - gxm), Iy = 0.5 * (gyp - gym), err = irf - gcc;
+              prod[0 * npad + pix] = Ix * Ix;
+              prod[1 * npad + pix] = Ix * Iy;
+              prod[2 * npad + pix] = Iy * Iy;
+              prod[3 * npad + pix] = Ix * err;
+              prod[4 * npad + pix] = Iy * err;
+            }
+          };
+          // one accumulator per lane 0..4; the lanes above repeat lane 4's chain, so that no EXEC change separates the adds from
+          // the instructions they are meant to be scheduled between
+          const double2* cq = reinterpret_cast<const double2*>(prod + (lane < 5 ? lane : 4) * npad);
+          auto chain = [&](int i0, int cnt) {  // pairs i0 .. i0 + cnt - 1 of the accumulator's products, in order
+            double2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+              if (k < cnt) v[k] = cq[i0 + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+              if (k < cnt) { acc += v[k].x; acc += v[k].y; }
+          };
+          // ---- first half: grid rounds 0..PR1-1, products of pixels 0..63
+#pragma unroll
+          for (int k = 0; k < PR1; k++) taps_of(k);
+#pragma unroll
+          for (int k = 0; k < PR1; k++) pixels_of(k);
+#pragma unroll
+          for (int k = 0; k < PR1; k++) lerp_store(k);
+          __syncthreads();
+          stamp(1);
+          product_reads(0);
+          product_stores(0);
+          __syncthreads();
+          stamp(2);
+          // ---- second half of the grid and of the products, with the 64 ordered adds over pixels 0..63 in between: the adds are a
+          // chain of dependent instructions (~10 cycles each) that leaves the issue slots free for everything else
+#pragma unroll
+          for (int k = PR1; k < NSR; k++) taps_of(k);
+          chain(0, 8);
+#pragma unroll
+          for (int k = PR1; k < NSR; k++) pixels_of(k);
+          chain(8, 8);
+#pragma unroll
+          for (int k = PR1; k < NSR; k++) lerp_store(k);
+          chain(16, 8);
+          product_reads(1);  // after the stores of the grid's second half (same wave: LDS operations keep their order)
+          chain(24, 8);
+          product_stores(1);
+          __syncthreads();
+          // ---- the rest of the ordered sums: pixels 64..npix-1
+#pragma unroll
+          for (int i0 = 32; i0 < npix / 2; i0 += 8) chain(i0, npix / 2 - i0 < 8 ? npix / 2 - i0 : 8);
+          if (npix & 1) acc += prod[(lane < 5 ? lane : 4) * npad + npix - 1];
+          __syncthreads();  // products consumed; next iteration may overwrite
+          stamp(3);
+        } else {
         // ---- I1 on the grid and I0 on its centre: one sample per lane and round (T:183-198, rows first).  All tap reads,
         // then all pixel reads, then the arithmetic, then the stores: LDS stores between the rounds would order every
         // later LDS read behind them (one LDS round trip per dependent access instead of three in total).
@@ -354,7 +477,7 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
           }
 #pragma unroll
           for (int k = 0; k < L::SR; k++)
-            if (k + 1 < L::SR || samp_ok_last) samp_out[k][0] = val[k];  // only the last round has lanes without a sample
+            if (samp_ok[k]) samp_out[k][0] = val[k];  // (only the last round has lanes without a sample)
         }
         __syncthreads();
         stamp(1);  // coordinate check + grid
@@ -404,7 +527,6 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         __syncthreads();
         stamp(2);  // products
         // ---- ordered sums: lane k < 5 adds accumulator k's products in reference order
-        double acc = 0.0;
         if (lane < 5) {
           const double2* q = reinterpret_cast<const double2*>(prod + lane * npad);
           // compile-time trip count: the LDS reads are hoisted in batches ahead of the dependent adds
@@ -423,6 +545,7 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         }
         __syncthreads();  // products consumed; next iteration may overwrite
         stamp(3);  // ordered sums
+        }
         const double A00 = readlane_f64(acc, 0), A01 = readlane_f64(acc, 1), A11 = readlane_f64(acc, 2);
         const double b0 = readlane_f64(acc, 3), b1 = readlane_f64(acc, 4);
         // ---- 2x2 solve (T:451-459): inv00 = A11/detA, inv01 = -A01/detA, inv11 = A00/detA in lanes 0, 1, 2 of ONE division
@@ -897,13 +1020,20 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
     if (stamps_on && RR == 5) k_klt_track<5, true><<<n, 64, klt_lds_bytes<5>(), c->stream>>>(KLT_ARGS); \
     else k_klt_track<RR, false><<<n, 64, klt_lds_bytes<RR>(), c->stream>>>(KLT_ARGS);               \
   } while (0)
+#define KLT_LAUNCH_PIPE(RR)                                                                                        \
+  do {                                                                                                             \
+    if (stamps_on && RR == 5) k_klt_track<5, true, true><<<n, 64, klt_lds_bytes<5>(), c->stream>>>(KLT_ARGS);      \
+    else k_klt_track<RR, false, true><<<n, 64, klt_lds_bytes<RR>(), c->stream>>>(KLT_ARGS);                        \
+  } while (0)
+  // SFMX_KLT_PIPE=0|1: the ordered sums of the first 64 pixels scheduled under the second half of the sample grid (radius 4 / 5)
+  const bool pipe = getenv("SFMX_KLT_PIPE") ? getenv("SFMX_KLT_PIPE")[0] == '1' : false;
   if (K == 0) {
     switch (r) {
       case 1: KLT_LAUNCH(1); break;
       case 2: KLT_LAUNCH(2); break;
       case 3: KLT_LAUNCH(3); break;
-      case 4: KLT_LAUNCH(4); break;
-      case 5: KLT_LAUNCH(5); break;
+      case 4: if (pipe) KLT_LAUNCH_PIPE(4); else KLT_LAUNCH(4); break;
+      case 5: if (pipe) KLT_LAUNCH_PIPE(5); else KLT_LAUNCH(5); break;
       case 6: KLT_LAUNCH(6); break;
       default: KLT_LAUNCH(7); break;
     }
@@ -918,6 +1048,7 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
     }
   }
 #undef KLT_LAUNCH
+#undef KLT_LAUNCH_PIPE
 #undef KLT_LAUNCH_K
 #undef KLT_LAUNCH_M
 #undef KLT_ARGS
