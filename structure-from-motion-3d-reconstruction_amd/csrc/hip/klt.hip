@@ -20,7 +20,9 @@
 //    A step with more extra coordinates than the descriptor table holds takes the per-pixel path.
 //  * ordered reduction (serial by contract): FP64 addition is not associative and parity is
 //    bit-exact, so the (2r+1)^2 products of each accumulator are added in the reference's
-//    (dy outer, dx inner) sequence: lanes 0..4 each walk one accumulator's products in LDS.
+//    (dy outer, dx inner) sequence -- by default as chains of v_mfma_f64_4x4x4 with B = 1.0 (one matrix instruction = four
+//    fused multiply-adds in ascending k, each rounded to FP64: four of the reference's additions for 16 accumulators; measured,
+//    tools/probes/mfma_f64_order.hip), or as v_add_f64 chains in lanes 0..4 (SFMX_KLT_SUMS=valu, and for radius 1).
 //  * 2x2 solve (the three divisions of T:453-455 in three lanes of one instruction), hypot-based stop test
 //    (glibc-compatible hypot, sfmx_math.h), level loop, then the backward pass from the forward result and
 //    keep = !(hypot(back - p0) >= fb_thresh).
@@ -143,10 +145,12 @@ __device__ __forceinline__ int book_floor(double v) {
   return (int)floor(v);
 }
 
-// LDS plan of one track (one wavefront) for window radius r
-template <int r>
+// LDS plan of one track (one wavefront) for window radius r.  MS (ordered sums on the FP64 matrix core): the product rows are
+// padded to a multiple of four entries and a sixth row holds zeros (operand lanes without an accumulator read it).
+template <int r, bool MS = false>
 struct KltLds {
-  static constexpr int side = 2 * r + 1, npix = side * side, npad = (npix + 1) & ~1;
+  static constexpr int side = 2 * r + 1, npix = side * side, npad = MS ? ((npix + 3) & ~3) : ((npix + 1) & ~1);
+  static constexpr int prows = MS ? 6 : 5;
   static constexpr int PS = KLT_PS_FOR(r);
   static constexpr int NCAN = 2 * r + 3;        // grid coordinates per axis: slot 0 = fl(fl(x-r)-1), slot s = fl(x+s-1-r), slot 2r+2 = fl(fl(x+r)+1)
   static constexpr int GS = NCAN + 1;           // grid row stride (doubles)
@@ -154,7 +158,7 @@ struct KltLds {
   static constexpr size_t o_g1 = (size_t)win_floats * 4;         // double G1[GS][GS]: I1 on the grid
   static constexpr size_t o_g0 = o_g1 + (size_t)GS * GS * 8;     // double G0[GS][GS]: I0 on the grid
   static constexpr size_t o_prod = o_g0 + (size_t)GS * GS * 8;   // double prod[5][npad]
-  static constexpr size_t o_tapf = o_prod + (size_t)5 * npad * 8; // double2 {f, 1-f} ({0, 0} outside the image) [2 axes][32]: taps of the grid slots
+  static constexpr size_t o_tapf = o_prod + (size_t)prows * npad * 8; // double2 {f, 1-f} ({0, 0} outside the image) [2 axes][32]: taps of the grid slots
   static constexpr size_t o_tapi = o_tapf + (size_t)2 * 32 * 16;  // int byte offset of the tap's column / row inside a window, [2][32]
   static constexpr size_t o_xtapf = o_tapi + (size_t)2 * 32 * 4;   // double2 taps of off-grid neighbours fl(c_d + 1) / fl(c_d - 1): [2 kinds][2 axes][16]
   static constexpr size_t o_xtapi = o_xtapf + (size_t)2 * 2 * 16 * 16;  // their byte offsets
@@ -193,7 +197,8 @@ __device__ __forceinline__ double lerp_lds(const float* __restrict__ win, const 
 // into stamps[0..7] (a buffer nothing else reads); the production instantiation has no stamp code.
 // PIPE (window radius 4 and 5: 64 < npix <= 128): the ordered sums over the first 64 pixels run UNDER the second half of the sample
 // grid and of the products -- see the PIPE branch below.  Same arithmetic, another instruction order.
-template <int r, bool STAMP, bool PIPE = false>
+// MSUM: the ordered sums as chains of v_mfma_f64_4x4x4 with B = 1.0 -- see the MSUM branch below.
+template <int r, bool STAMP, bool PIPE = false, bool MSUM = false>
 __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const double* __restrict__ xy_in, int n, int levels,
                                                   int iters, double fb_thresh, double* __restrict__ xy_fwd,
                                                   double* __restrict__ xy_back, uint8_t* __restrict__ keep,
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
   // wave priority (s_setprio, 0..3): above the bulk kernels of the other lanes, below the BA chain (3)
   if (wave_prio == 1) __builtin_amdgcn_s_setprio(1);
   else if (wave_prio == 2) __builtin_amdgcn_s_setprio(2);
-  using L = KltLds<r>;
+  using L = KltLds<r, MSUM>;
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
   auto stamp = [&](int k) {
     if (STAMP) {
@@ -266,6 +271,12 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
   const double p0x = xy_in[2 * track], p0y = xy_in[2 * track + 1];
   double px = p0x, py = p0y;
   unsigned int steps = 0, slow_steps = 0;
+  if constexpr (MSUM) {  // the zero row and the pad entries of the product rows: written once, never by the products
+    for (int i = lane; i < npad; i += 64) prod[5 * npad + i] = 0.0;
+    constexpr int NPADS = npad - npix;  // 3 for every odd window side
+    if (NPADS > 0 && lane < 5 * NPADS) prod[(lane / (NPADS > 0 ? NPADS : 1)) * npad + npix + lane % (NPADS > 0 ? NPADS : 1)] = 0.0;
+    __syncthreads();
+  }
   // lane roles of the coordinate check: lanes 0..31 the x axis, 32..63 the y axis, lane (axis, dt) owns offset d = dt - r
   const int dt = lane & 31, daxis = lane >> 5;
 
@@ -403,17 +414,31 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
               prod[4 * npad + pix] = Iy * err;
             }
           };
-          // one accumulator per lane 0..4; the lanes above repeat lane 4's chain, so that no EXEC change separates the adds from
-          // the instructions they are meant to be scheduled between
+          // VALU sums: one accumulator per lane 0..4; the lanes above repeat lane 4's chain, so that no EXEC change separates the
+          // adds from the instructions they are meant to be scheduled between.  Matrix-core sums (MSUM, see the plain schedule
+          // below for the operand layout): the chain instructions run in their own pipe, next to the VALU work between them.
+          // A chain unit is a pair of addends (VALU) or a group of four (MSUM); the first 64 pixels are 4 * CU units.
+          constexpr int CU = MSUM ? 4 : 8, CTOT = MSUM ? npad / 4 : npix / 2;
           const double2* cq = reinterpret_cast<const double2*>(prod + (lane < 5 ? lane : 4) * npad);
-          auto chain = [&](int i0, int cnt) {  // pairs i0 .. i0 + cnt - 1 of the accumulator's products, in order
-            double2 v[8];
+          const double* mq = prod + ((lane & 15) < 5 ? (lane & 15) : 5) * npad + (lane >> 4);
+          auto chain = [&](int i0, int cnt) {  // units i0 .. i0 + cnt - 1 of the accumulator's products, in order
+            if constexpr (MSUM) {
+              double v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-              if (k < cnt) v[k] = cq[i0 + k];
+              for (int k = 0; k < 8; k++)
+                if (k < cnt) v[k] = mq[4 * (i0 + k)];
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-              if (k < cnt) { acc += v[k].x; acc += v[k].y; }
+              for (int k = 0; k < 8; k++)
+                if (k < cnt) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(v[k], 1.0, acc, 0, 0, 0);
+            } else {
+              double2 v[8];
+#pragma unroll
+              for (int k = 0; k < 8; k++)
+                if (k < cnt) v[k] = cq[i0 + k];
+#pragma unroll
+              for (int k = 0; k < 8; k++)
+                if (k < cnt) { acc += v[k].x; acc += v[k].y; }
+            }
           };
           // ---- first half: grid rounds 0..PR1-1, products of pixels 0..63
 #pragma unroll
@@ -432,21 +457,21 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
           // chain of dependent instructions (~10 cycles each) that leaves the issue slots free for everything else
 #pragma unroll
           for (int k = PR1; k < NSR; k++) taps_of(k);
-          chain(0, 8);
+          chain(0, CU);
 #pragma unroll
           for (int k = PR1; k < NSR; k++) pixels_of(k);
-          chain(8, 8);
+          chain(CU, CU);
 #pragma unroll
           for (int k = PR1; k < NSR; k++) lerp_store(k);
-          chain(16, 8);
+          chain(2 * CU, CU);
           product_reads(1);  // after the stores of the grid's second half (same wave: LDS operations keep their order)
-          chain(24, 8);
+          chain(3 * CU, CU);
           product_stores(1);
           __syncthreads();
           // ---- the rest of the ordered sums: pixels 64..npix-1
 #pragma unroll
-          for (int i0 = 32; i0 < npix / 2; i0 += 8) chain(i0, npix / 2 - i0 < 8 ? npix / 2 - i0 : 8);
-          if (npix & 1) acc += prod[(lane < 5 ? lane : 4) * npad + npix - 1];
+          for (int i0 = 4 * CU; i0 < CTOT; i0 += 8) chain(i0, CTOT - i0 < 8 ? CTOT - i0 : 8);
+          if (!MSUM && (npix & 1)) acc += prod[(lane < 5 ? lane : 4) * npad + npix - 1];
           __syncthreads();  // products consumed; next iteration may overwrite
           stamp(3);
         } else {
@@ -526,7 +551,33 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         }
         __syncthreads();
         stamp(2);  // products
-        // ---- ordered sums: lane k < 5 adds accumulator k's products in reference order
+        // ---- ordered sums
+        if constexpr (MSUM) {
+          // On the FP64 matrix core: v_mfma_f64_4x4x4 computes D[b][i][j] = C[b][i][j] + sum_k A[b][i][k] B[b][k][j] as four fused
+          // multiply-adds in ascending k, each rounded to FP64 (measured on gfx950 over 1.28 M random sums: always the sequential
+          // result, denormals kept, signed zeros as IEEE; tools/probes/mfma_f64_order.hip, profiles/r03_mfma_f64_order_probe.txt).
+          // With B = 1.0 a product is exact and the instruction performs FOUR of the reference's ordered additions for 16
+          // accumulators: acc_a <- (((acc_a + p[a][4s]) + p[a][4s+1]) + p[a][4s+2]) + p[a][4s+3].  Operand lane 16k + 4b + i holds
+          // A[b][i][k]: accumulator a = 4b + i, addend 4s + k; rows a >= 5 read the zero row, the pad addends are +0.0 (an
+          // accumulator that started at +0.0 is never -0.0, so x + (+0.0) = x).  D[b][i][j] sits in lane 16i + 4b + j.
+          const int mk = lane >> 4, ma = lane & 15;
+          const double* q = prod + (ma < 5 ? ma : 5) * npad + mk;
+          // all operands are requested before the first instruction of the chain (the scheduler otherwise keeps two reads in
+          // flight and the chain waits an LDS round trip for every other instruction)
+          constexpr int NQ = npad / 4, CH = 32;
+#pragma unroll
+          for (int i0 = 0; i0 < NQ; i0 += CH) {
+            double v[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+              if (i0 + k < NQ) v[k] = q[4 * (i0 + k)];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < CH; k++)
+              if (i0 + k < NQ) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(v[k], 1.0, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else
         if (lane < 5) {
           const double2* q = reinterpret_cast<const double2*>(prod + lane * npad);
           // compile-time trip count: the LDS reads are hoisted in batches ahead of the dependent adds
@@ -546,8 +597,10 @@ __global__ __launch_bounds__(64) void k_klt_track(PyrDesc A, PyrDesc B, const do
         __syncthreads();  // products consumed; next iteration may overwrite
         stamp(3);  // ordered sums
         }
-        const double A00 = readlane_f64(acc, 0), A01 = readlane_f64(acc, 1), A11 = readlane_f64(acc, 2);
-        const double b0 = readlane_f64(acc, 3), b1 = readlane_f64(acc, 4);
+        // accumulator a: lane a of the VALU chains, lane 16 (a & 3) + 4 (a >> 2) of the matrix-core result
+        constexpr int LA0 = 0, LA1 = MSUM ? 16 : 1, LA2 = MSUM ? 32 : 2, LA3 = MSUM ? 48 : 3, LA4 = 4;
+        const double A00 = readlane_f64(acc, LA0), A01 = readlane_f64(acc, LA1), A11 = readlane_f64(acc, LA2);
+        const double b0 = readlane_f64(acc, LA3), b1 = readlane_f64(acc, LA4);
         // ---- 2x2 solve (T:451-459): inv00 = A11/detA, inv01 = -A01/detA, inv11 = A00/detA in lanes 0, 1, 2 of ONE division
         double sx = 0.0, sy = 0.0;
         const double detA = A00 * A11 - A01 * A01;
@@ -1020,14 +1073,47 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
     if (stamps_on && RR == 5) k_klt_track<5, true><<<n, 64, klt_lds_bytes<5>(), c->stream>>>(KLT_ARGS); \
     else k_klt_track<RR, false><<<n, 64, klt_lds_bytes<RR>(), c->stream>>>(KLT_ARGS);               \
   } while (0)
+#define KLT_LAUNCH_MSUM(RR)                                                                                              \
+  do {                                                                                                                   \
+    constexpr size_t lds = KltLds<RR, true>::bytes;                                                                      \
+    if (stamps_on && RR == 5) k_klt_track<5, true, false, true><<<n, 64, KltLds<5, true>::bytes, c->stream>>>(KLT_ARGS);  \
+    else k_klt_track<RR, false, false, true><<<n, 64, lds, c->stream>>>(KLT_ARGS);                                       \
+  } while (0)
+#define KLT_LAUNCH_PIPE_MSUM(RR)                                                                                             \
+  do {                                                                                                                       \
+    constexpr size_t lds = KltLds<RR, true>::bytes;                                                                          \
+    if (stamps_on && RR == 5) k_klt_track<5, true, true, true><<<n, 64, KltLds<5, true>::bytes, c->stream>>>(KLT_ARGS);       \
+    else k_klt_track<RR, false, true, true><<<n, 64, lds, c->stream>>>(KLT_ARGS);                                            \
+  } while (0)
 #define KLT_LAUNCH_PIPE(RR)                                                                                        \
   do {                                                                                                             \
     if (stamps_on && RR == 5) k_klt_track<5, true, true><<<n, 64, klt_lds_bytes<5>(), c->stream>>>(KLT_ARGS);      \
     else k_klt_track<RR, false, true><<<n, 64, klt_lds_bytes<RR>(), c->stream>>>(KLT_ARGS);                        \
   } while (0)
-  // SFMX_KLT_PIPE=0|1: the ordered sums of the first 64 pixels scheduled under the second half of the sample grid (radius 4 / 5)
-  const bool pipe = getenv("SFMX_KLT_PIPE") ? getenv("SFMX_KLT_PIPE")[0] == '1' : false;
-  if (K == 0) {
+  // Schedule of the ordered sums (identical results, measured in profiles/r03_klt_variants_probe.txt):
+  //   SFMX_KLT_SUMS=mfma|valu  chains of FP64 matrix-core instructions (default from radius 2: 4-8 % shorter launches, and the
+  //                            121 additions of a step leave the VALU) or of v_add_f64 in lanes 0..4;
+  //   SFMX_KLT_PIPE=0|1        the sums over the first 64 pixels issued under the second half of the sample grid (radius 4 / 5);
+  //                            default: with the matrix-core sums at radius 5 when the launch holds one to 2.5 waves per SIMD
+  //                            (167 against 174 us at T = 1 564; slower for a lone wave and above ~3 waves per SIMD).
+  const char* sums_env = getenv("SFMX_KLT_SUMS");
+  const char* pipe_env = getenv("SFMX_KLT_PIPE");
+  const bool msum = sums_env ? sums_env[0] == 'm' : r >= 2;
+  const bool pipe = pipe_env ? pipe_env[0] == '1' : (msum && r == 5 && n >= 1100 && n < 2600);
+  if (K == 0 && msum && pipe && (r == 4 || r == 5)) {
+    if (r == 4) KLT_LAUNCH_PIPE_MSUM(4);
+    else KLT_LAUNCH_PIPE_MSUM(5);
+  } else if (K == 0 && msum) {
+    switch (r) {
+      case 1: KLT_LAUNCH_MSUM(1); break;
+      case 2: KLT_LAUNCH_MSUM(2); break;
+      case 3: KLT_LAUNCH_MSUM(3); break;
+      case 4: KLT_LAUNCH_MSUM(4); break;
+      case 5: KLT_LAUNCH_MSUM(5); break;
+      case 6: KLT_LAUNCH_MSUM(6); break;
+      default: KLT_LAUNCH_MSUM(7); break;
+    }
+  } else if (K == 0) {
     switch (r) {
       case 1: KLT_LAUNCH(1); break;
       case 2: KLT_LAUNCH(2); break;
@@ -1049,6 +1135,8 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   }
 #undef KLT_LAUNCH
 #undef KLT_LAUNCH_PIPE
+#undef KLT_LAUNCH_MSUM
+#undef KLT_LAUNCH_PIPE_MSUM
 #undef KLT_LAUNCH_K
 #undef KLT_LAUNCH_M
 #undef KLT_ARGS
