@@ -22,6 +22,7 @@
 #include "sfmx_internal.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define HG 16  // lanes per hypothesis
@@ -213,6 +214,16 @@ __device__ __forceinline__ void pivot_combine_key(unsigned long long& k) {
   k = o > k ? o : k;
 }
 
+// 16-lane all-reduce maximum of an unsigned word: four v_max_u32 with a DPP operand (0 is the identity of the unsigned maximum,
+// so the cross-lane move folds into the instruction)
+__device__ __forceinline__ unsigned row_umax(unsigned x) {
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false));  // row_mirror
+  return x;
+}
+
 struct HypLds {
   double D[72];   // 8x9 design matrix
   double A[81];   // AtA, rotated in place
@@ -221,10 +232,12 @@ struct HypLds {
   double A3[9], V3[9];
 };
 
+template <bool LEAN, bool STAMP = false>
 __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi, const double* __restrict__ xj, int n,
                                                    const int32_t* __restrict__ idx8, int H, int sweeps, double* __restrict__ E_out,
-                                                   double* __restrict__ cond_out) {
+                                                   double* __restrict__ cond_out, unsigned long long* __restrict__ ticks) {
   __shared__ HypLds lds[HPW];
+  const unsigned long long t_kernel = ticks ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = threadIdx.x, g = lane / HG, t = lane % HG;
   const int hyp = blockIdx.x * HPW + g;
   const bool live = hyp < H;
@@ -274,30 +287,76 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
     own_code[k] = 16 * i + j;
   }
   const bool third = t < 4;
+  unsigned long long t_begin = 0, tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+  unsigned int n_rot = 0;
+  if (ticks) t_begin = __builtin_amdgcn_s_memtime();
+  auto stamp = [&](int k) {  // STAMP build only: s_memtime deltas per phase of the rotation loop
+    if (STAMP) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tph[k] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (STAMP) tlast = t_begin;
   bool active = live;
-  bool near_tie = false;  // uniform within the 16-lane group
+  bool near_tie = false;  // uniform within the 16-lane group (LEAN: per lane until the loop has ended)
   const unsigned long long gmask = 0xffffull << (HG * g);  // this hypothesis' lanes in a wave-wide ballot
   for (int it = 0; it < sweeps; ++it) {
     // ---- pivot: arg-max of |a_ij| over the upper triangle, first in row-major order among equals.  The 16 lanes reduce
     // ONE 64-bit key per entry -- the magnitude's bit pattern with its low byte replaced by 255 - code -- with integer
     // compares (a (value, code) pair costs two FP64 compares per step).  Magnitudes that differ only in the byte that
     // was given up are nearly tied by any standard: such a hypothesis is flagged below and re-derived on the host.
-    const double v0 = fabs(L.A[own_off[0]]), v1 = fabs(L.A[own_off[1]]), v2 = third ? fabs(L.A[own_off[2]]) : 0.0;
+    double v0, v1, v2;
     unsigned long long kb;
-    {
+    if constexpr (LEAN) {
+      // (the third read is unconditional -- its address is a valid entry for every lane -- and selected afterwards: a branch around
+      // it costs an LDS wait of its own.  A NaN magnitude is not filtered: its bit pattern wins the maximum, `bv` below is NaN and
+      // the hypothesis goes to the host, which is where a matrix with a NaN belongs.)
+      const double a2 = L.A[own_off[2]];
+      v0 = fabs(L.A[own_off[0]]);
+      v1 = fabs(L.A[own_off[1]]);
+      v2 = third ? fabs(a2) : 0.0;
+      const unsigned long long k0 = ((unsigned long long)__double_as_longlong(v0) & ~0xffull) | (unsigned)(255 - own_code[0]);
+      const unsigned long long k1 = ((unsigned long long)__double_as_longlong(v1) & ~0xffull) | (unsigned)(255 - own_code[1]);
+      const unsigned long long k2 = ((unsigned long long)__double_as_longlong(v2) & ~0xffull) | (unsigned)(255 - own_code[2]);
+      kb = k0 > k1 ? k0 : k1;
+      kb = kb > k2 ? kb : k2;
+    } else {
+      v0 = fabs(L.A[own_off[0]]);
+      v1 = fabs(L.A[own_off[1]]);
+      v2 = third ? fabs(L.A[own_off[2]]) : 0.0;
       const unsigned long long k0 = (((v0 == v0) ? (unsigned long long)__double_as_longlong(v0) : 0ull) & ~0xffull) | (unsigned)(255 - own_code[0]);
       const unsigned long long k1 = (((v1 == v1) ? (unsigned long long)__double_as_longlong(v1) : 0ull) & ~0xffull) | (unsigned)(255 - own_code[1]);
       const unsigned long long k2 = (((v2 == v2) ? (unsigned long long)__double_as_longlong(v2) : 0ull) & ~0xffull) | (unsigned)(255 - own_code[2]);
       kb = k0 > k1 ? k0 : k1;
       kb = kb > k2 ? kb : k2;
     }
-    pivot_combine_key<0xB1>(kb);   // quad_perm [1,0,3,2]
-    pivot_combine_key<0x4E>(kb);   // quad_perm [2,3,0,1]
-    pivot_combine_key<0x141>(kb);  // row_half_mirror
-    pivot_combine_key<0x140>(kb);  // row_mirror
+    stamp(0);  // own entries + keys
+    // the 64-bit maximum in two 32-bit passes (ten instructions instead of twenty-eight for four 64-bit compare / select steps):
+    // the high words first, then the low words of the lanes that hold the maximal high word
+    {
+      const unsigned khi = (unsigned)(kb >> 32), klo = (unsigned)kb;
+      const unsigned mhi = row_umax(khi);
+      const unsigned mlo = row_umax(khi == mhi ? klo : 0u);
+      kb = ((unsigned long long)mhi << 32) | mlo;
+    }
     const int code = 255 - (int)(kb & 0xffull);
     const double bv = __longlong_as_double((long long)(kb & ~0xffull));  // the maximum, up to its last byte
     const int p = code >> 4, q = code & 15;
+    if constexpr (LEAN) {
+      // maxv < 1e-12 -> break (linalg.hpp:150).  Every lane of the group holds the group's maximum up to its last byte: bv <= max <=
+      // bvh.  Both on one side of 1e-12 decide the test without another reduction; straddling it (or NaN) cannot be decided from
+      // the key -- that hypothesis is flagged and re-derived on the host.
+      const double bvh = __longlong_as_double((long long)(kb | 0xffull));
+      const bool ge = bv >= 1e-12, lt = bvh < 1e-12;
+      near_tie |= active & !(ge | lt);
+      active = active & ge;
+      if (!__any(active)) break;
+      // a second entry within PIVOT_TIE_BAND of the chosen pivot?  Flag kept per lane, combined over the group after the loop
+      const double band = bv * (1.0 - PIVOT_TIE_BAND);
+      near_tie |= active & (((v0 >= band) & (own_code[0] != code)) | ((v1 >= band) & (own_code[1] != code)) |
+                            (third & (v2 >= band) & (own_code[2] != code)));
+    } else {
     // maxv < 1e-12 -> break (linalg.hpp:150), decided on the exact magnitudes: no entry of this hypothesis reaches 1e-12
     const bool big = (v0 >= 1e-12) | (v1 >= 1e-12) | (v2 >= 1e-12);
     active = active & ((__ballot(big) & gmask) != 0);
@@ -308,14 +367,21 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
                                   (third & (v2 >= band) & (own_code[2] != code)));
       near_tie |= (__ballot(mine) & gmask) != 0;
     }
+    }
+    ++n_rot;
+    stamp(1);  // reduction, stop test, near-tie test
     if (active) {
       // all LDS reads of this rotation are issued together, ahead of the rotation-angle arithmetic
       const int tr = t < 9 ? t : 8;
       const double app = L.A[p * 9 + p], aqq = L.A[q * 9 + q], apq = L.A[p * 9 + q];
       const double vp = L.V[tr * 9 + p], vq = L.V[tr * 9 + q];
       const double akp = L.A[tr * 9 + p], akq = L.A[tr * 9 + q];
+      if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+      stamp(2);  // LDS reads of the rotation
       const Rot r = half_angle_fast(2.0 * apq, aqq - app);
       const double c = r.c, s = r.s;
+      if (STAMP) { asm volatile("" :: "v"(c), "v"(s)); }
+      stamp(3);  // rotation angle
       // every lane forms the off-diagonal pair of its row and the closed-form 2x2 pivot block
       // (J = [[c, s], [-s, c]] on (p,q): a_pp' = c^2 app - 2cs apq + s^2 aqq, a_qq' = s^2 app + 2cs apq + c^2 aqq);
       // which of them a lane stores is a select, not a branch (the four hypotheses of a wave have different p, q)
@@ -333,8 +399,18 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
         L.A[t * 9 + q] = w_tq; L.A[q * 9 + t] = w_tq;
       }
     }
+    stamp(4);  // rotation arithmetic, stores issued
     __syncthreads();
+    stamp(5);  // stores landed, barrier
   }
+  if (LEAN) near_tie = (__ballot(near_tie) & gmask) != 0;  // the lanes' flags -> the hypothesis' flag
+  if (ticks && lane == 0) {  // diagnostic (SFMX_RANSAC_TICKS=1|2): s_memtime ticks and rotations of this wave's loop (+ phases)
+    ticks[16 * blockIdx.x] = __builtin_amdgcn_s_memtime() - t_begin;
+    ticks[16 * blockIdx.x + 1] = n_rot;
+    for (int k = 0; k < 6; k++) ticks[16 * blockIdx.x + 2 + k] = tph[k];
+    ticks[16 * blockIdx.x + 8] = t_begin - t_kernel;  // design matrix, AtA
+  }
+  const unsigned long long t_tail = ticks ? __builtin_amdgcn_s_memtime() : 0ull;
   // ---- smallest eigenvector -> E -> rank 2 (one lane per hypothesis)
   if (live && t == 0) {
     // only the FIRST element of the stable ascending eigenvalue sort (linalg.hpp:188-191) is
@@ -361,6 +437,7 @@ __global__ __launch_bounds__(64) void k_hypotheses(const double* __restrict__ xi
     for (int r = 0; r < 9; r++) E_out[(size_t)hyp * 9 + r] = L.E[r];
     cond_out[hyp] = cond;
   }
+  if (ticks && lane == 0) ticks[16 * blockIdx.x + 9] = __builtin_amdgcn_s_memtime() - t_tail;  // eigenvector, rank-2 projection
 }
 
 // ------------------------------------------------------------------------------------------ scoring
@@ -521,8 +598,44 @@ int sfmx_ransac_score_ex(sfmx_ctx* c, const double* xi, const double* xj, int n,
   const double kfac = (S < 1e150 && thr > 0.0) ? 2.0 * (2.0 * S * S / sqrt(thr) + 4.0 * S) : INFINITY;
   KernelTimer t(c);
   t.start();
-  SFMX_PROF(c, KID_HYPOTHESES, (k_hypotheses<<<(H + HPW - 1) / HPW, 64, 0, c->stream>>>(d_xi, d_xj, n, d_idx, H, 120, d_E, d_cond)));
+  // SFMX_RANSAC_TICKS=1: s_memtime ticks per Jacobi rotation on stderr, =2: per phase of a rotation (stamped build; diagnostic,
+  // one extra synchronisation per call).  SFMX_RANSAC_HYP=legacy: the loop as of round 2 (A/B; identical results).
+  static const int ticks_mode = getenv("SFMX_RANSAC_TICKS") ? atoi(getenv("SFMX_RANSAC_TICKS")) : 0;
+  const bool hyp_legacy = getenv("SFMX_RANSAC_HYP") && strcmp(getenv("SFMX_RANSAC_HYP"), "legacy") == 0;
+  const int hyp_blocks = (H + HPW - 1) / HPW;
+  unsigned long long* d_ticks = nullptr;
+  if (ticks_mode) SFMX_HIP(c, hipMalloc(reinterpret_cast<void**>(&d_ticks), (size_t)hyp_blocks * 128));
+#define HYP_ARGS d_xi, d_xj, n, d_idx, H, 120, d_E, d_cond, d_ticks
+  if (ticks_mode == 2 && hyp_legacy) SFMX_PROF(c, KID_HYPOTHESES, (k_hypotheses<false, true><<<hyp_blocks, 64, 0, c->stream>>>(HYP_ARGS)));
+  else if (ticks_mode == 2) SFMX_PROF(c, KID_HYPOTHESES, (k_hypotheses<true, true><<<hyp_blocks, 64, 0, c->stream>>>(HYP_ARGS)));
+  else if (hyp_legacy) SFMX_PROF(c, KID_HYPOTHESES, (k_hypotheses<false><<<hyp_blocks, 64, 0, c->stream>>>(HYP_ARGS)));
+  else SFMX_PROF(c, KID_HYPOTHESES, (k_hypotheses<true><<<hyp_blocks, 64, 0, c->stream>>>(HYP_ARGS)));
+#undef HYP_ARGS
   SFMX_HIP(c, hipGetLastError());
+  if (ticks_mode) {
+    std::vector<unsigned long long> tk((size_t)hyp_blocks * 16);
+    SFMX_HIP(c, hipStreamSynchronize(c->stream));
+    SFMX_HIP(c, hipMemcpy(tk.data(), d_ticks, tk.size() * 8, hipMemcpyDeviceToHost));
+    SFMX_HIP(c, hipFree(d_ticks));
+    double sum_t = 0, sum_r = 0, max_t = 0, ph[6] = {0, 0, 0, 0, 0, 0}, setup = 0, tail = 0, tail_max = 0;
+    for (int b = 0; b < hyp_blocks; b++) {
+      sum_t += (double)tk[16 * b];
+      sum_r += (double)tk[16 * b + 1];
+      max_t = fmax(max_t, (double)tk[16 * b]);
+      for (int k = 0; k < 6; k++) ph[k] += (double)tk[16 * b + 2 + k];
+      setup += (double)tk[16 * b + 8];
+      tail += (double)tk[16 * b + 9];
+      tail_max = fmax(tail_max, (double)tk[16 * b + 9]);
+    }
+    const double per = sum_r > 0 ? 1.0 / sum_r : 0.0;
+    fprintf(stderr, "[sfmx] k_hypotheses<%s> H=%d: %.1f rotations per wave, %.0f ticks per rotation, slowest wave %.0f ticks", hyp_legacy ? "legacy" : "lean", H,
+            sum_r / hyp_blocks, sum_t * per, max_t);
+    fprintf(stderr, " | setup %.0f, tail %.0f (max %.0f) ticks per wave", setup / hyp_blocks, tail / hyp_blocks, tail_max);
+    if (ticks_mode == 2)
+      fprintf(stderr, " | own+keys %.0f | reduce+tests %.0f | lds reads %.0f | angle %.0f | rotate+stores %.0f | wait+barrier %.0f", ph[0] * per, ph[1] * per,
+              ph[2] * per, ph[3] * per, ph[4] * per, ph[5] * per);
+    fprintf(stderr, "\n");
+  }
   // exact E of the listed iterations -> staging patch area -> d[1]; returns the device pointer of the m x 9 block
   char* hpatch = hin + in_bytes;
   auto upload_exact = [&](const std::vector<int32_t>& its, const double** d_rows) -> int {

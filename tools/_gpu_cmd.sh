@@ -1,2 +1,1 @@
-python -m pytest tests -m gpu -x -q > gpurun_out/r03_r_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03_r_tests.log
-tail -1 gpurun_out/r03_r_tests.log | grep -q "rc=0" && python tools/microbench.py > gpurun_out/r03_r_microbench.txt 2>&1 && python bench.py > gpurun_out/r03_r_bench.json 2> gpurun_out/r03_r_bench.err
+SFMX_RANSAC_TICKS=1 timeout -k 10 300 python tools/ransac_hyp_probe.py > gpurun_out/r03_w_hyp_probe.txt 2> gpurun_out/r03_w_hyp_ticks.txt
