@@ -1943,13 +1943,11 @@ struct sfmx_pipeline_stats {
 
 // images_host and/or images_dev: [n][h][w] u8 (images_dev = device pointer, frames already in HBM).
 // out_dir may be NULL (no files).  centres_out (optional) [n_keyframes<=cap][3].
-int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void* images_dev, int n_images, int w, int h,
-                      const char* const* names, const double* K9, const double* lat, const double* lon, const std::uint8_t* has_ang,
-                      const sfmx_pipeline_cfg* cfg, const char* out_dir, char* log, int log_cap, sfmx_pipeline_stats* stats,
-                      double* centres_out, int centres_cap) {
+static int pipeline_run_body(sfmx_ctx* ctx, const std::uint8_t* images_host, const void* images_dev, int n_images, int w, int h,
+                             const char* const* names, const double* K9, const double* lat, const double* lon, const std::uint8_t* has_ang,
+                             const sfmx_pipeline_cfg* cfg, const char* out_dir, char* log, int log_cap, sfmx_pipeline_stats* stats,
+                             double* centres_out, int centres_cap, sfmx_host::Clock::time_point t_wall) {
   using namespace sfmx_host;
-  if (!ctx || !cfg || !K9 || (!images_host && !images_dev) || n_images <= 0) return SFMX_ERR_INVALID;
-  const auto t_wall = Clock::now();
   try {
     MemoryFrames src;
     src.host = images_host;
@@ -2007,6 +2005,20 @@ int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void
     if (log && log_cap > 0) std::snprintf(log, (size_t)log_cap, "ERROR: %s\n", e.what());
     return SFMX_ERR_INVALID;
   }
+}
+
+int sfmx_pipeline_run(sfmx_ctx* ctx, const std::uint8_t* images_host, const void* images_dev, int n_images, int w, int h,
+                      const char* const* names, const double* K9, const double* lat, const double* lon, const std::uint8_t* has_ang,
+                      const sfmx_pipeline_cfg* cfg, const char* out_dir, char* log, int log_cap, sfmx_pipeline_stats* stats,
+                      double* centres_out, int centres_cap) {
+  using namespace sfmx_host;
+  if (!ctx || !cfg || !K9 || (!images_host && !images_dev) || n_images <= 0) return SFMX_ERR_INVALID;
+  const auto t_wall = Clock::now();
+  const int rc = pipeline_run_body(ctx, images_host, images_dev, n_images, w, h, names, K9, lat, lon, has_ang, cfg, out_dir, log, log_cap, stats,
+                                   centres_out, centres_cap, t_wall);
+  // the body's locals (map, keyframes, track histories) are gone here
+  if (std::getenv("SFMX_TRACE_PHASES")) std::fprintf(stderr, "phase %-22s %8.3f ms (since entry)\n", "results released", since(t_wall) * 1e3);
+  return rc;
 }
 
 // frees the helper contexts kept for reuse by later sfmx_pipeline_run calls

@@ -1,1 +1,1 @@
-SFMX_RANSAC_TICKS=1 timeout -k 10 300 python tools/ransac_hyp_probe.py > gpurun_out/r03_w_hyp_probe.txt 2> gpurun_out/r03_w_hyp_ticks.txt
+SFMX_TRACE_PHASES=1 timeout -k 10 300 python tools/pass_times.py > gpurun_out/r03_z_pass_times.txt 2>&1

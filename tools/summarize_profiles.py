@@ -17,7 +17,7 @@ if pmc_dir:
     def load(sub):
         return list(csv.DictReader(open(glob.glob(os.path.join(pmc_dir, sub, "*", "*counter_collection.csv"))[0])))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for sub in ("fetch", "write", "sq"):
+    for sub in ("fetch", "write", "sq", "mfma"):
         try:
             for r in load(sub):
                 agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
