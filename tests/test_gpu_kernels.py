@@ -187,6 +187,66 @@ def test_corner_pick_for_every_min_distance_vs_oracle(ctx, min_distance):
     To.close()
 
 
+def test_fp64_matrix_core_adds_in_order():
+    """What the KLT kernel's ordered sums rest on (csrc/hip/klt.hip, MSUM): v_mfma_f64_4x4x4 applies its four k-terms as fused
+    multiply-adds in ascending k, each rounded to FP64 -- with B = 1.0 four of the reference's additions in order -- keeps
+    denormal addends and never produces -0 from +0.  Measured by the stand-alone probe (tools/probes/mfma_f64_order.hip)."""
+    import subprocess
+    exe = os.path.join(H.ROOT, H.PKG_NAME, "_build", "probes", "mfma_f64_order")
+    if not os.path.exists(exe):  # normally built by __graft_entry__.build() / make all
+        subprocess.run(["make", "-C", os.path.join(H.ROOT, H.PKG_NAME, "csrc"), "probes"], check=True, capture_output=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    import re
+    m = re.search(r"4x4x4f64 rounding over (\d+) sums.*sequential-ascending (\d+), sequential-descending (\d+), wide-then-round (\d+), other (\d+)", p.stdout)
+    assert m, p.stdout[-2000:]
+    n, seq, rev, wide, other = map(int, m.groups())
+    assert n >= 1000000 and seq == n and rev == wide == other == 0, m.group(0)
+    m16 = re.search(r"16x16x4f64 rounding: sequential k=0..3 (\d+), sequential k=3..0 (\d+), wide-then-round (\d+), other (\d+)", p.stdout)
+    assert m16 and int(m16.group(1)) > 0 and m16.group(2) == m16.group(3) == m16.group(4) == "0", p.stdout[-2000:]
+    assert "denormal addend kept: yes" in p.stdout and "0 of 64 results have the sign bit" in p.stdout, p.stdout[-2000:]
+    # operand / result lanes the kernel assumes: A[b][i][k] in lane 16 k + 4 b + i, D[b][i][j] in lane 16 i + 4 b + j
+    assert re.search(r"^A 1: B0->D16, B1->D17, B2->D18, B3->D19,$", p.stdout, re.M) and re.search(r"^A16: B16->D0, B17->D1, B18->D2, B19->D3,$", p.stdout, re.M)
+    assert re.search(r"^A 4: B4->D4, B5->D5, B6->D6, B7->D7,$", p.stdout, re.M)
+
+
+@pytest.mark.parametrize("radius", [1, 2, 4, 5, 7])
+def test_klt_sum_schedules_vs_oracle(ctx, radius, monkeypatch):
+    """Every schedule of the ordered sums -- FP64 matrix core (default from radius 2), VALU chains, each with and without the
+    pipelined first half (radius 4 / 5) -- against the oracle, bit for bit: interior tracks, tracks on and beyond the image
+    border, far-away and NaN coordinates (T:402-460)."""
+    seq = synth.make_sequence(2, 640, 480, 0.3, n_blobs=20000, seed=11)
+    a, b = seq["images"]
+    pts = H.shi_tomasi(O, "orc", a, 150, 0.01, 8)
+    edge = np.array([[0.2, 0.3], [639.5, 479.5], [-3.0, 10.0], [5.0, -2.5], [638.9, 100.0], [100.0, 478.7], [1e12, 5.0], [np.nan, 7.0],
+                     [320.0, 240.0], [-40.0, -40.0], [700.0, 500.0], [15.5, 15.5], [16.0, 464.0]])
+    pts = np.ascontiguousarray(np.concatenate([pts, edge]))
+    pa, pb = ctx.pyramid(a, 3), ctx.pyramid(b, 3)
+    efwd, eback, ekeep = H.klt_track(O, "orc", a, b, 3, radius, 6, pts, 1.0)
+    for sums in ("mfma", "valu"):
+        for pipe_ in ("0", "1"):
+            monkeypatch.setenv("SFMX_KLT_SUMS", sums)
+            monkeypatch.setenv("SFMX_KLT_PIPE", pipe_)
+            fwd, back, keep, steps = ctx.klt_track(pa, pb, pts, 3, radius, 6, 1.0)
+            H.assert_bits_equal(fwd, efwd, f"fwd sums={sums} pipe={pipe_}", nan_equal=True)
+            H.assert_bits_equal(back, eback, f"back sums={sums} pipe={pipe_}", nan_equal=True)
+            assert np.array_equal(keep, ekeep), (sums, pipe_)
+
+
+def test_hypothesis_loop_variants_identical(ctx, golden, monkeypatch):
+    """k_hypotheses: this round's rotation loop (two-pass key maximum, stop / near-tie tests from the reduced key) and the round-2
+    loop (SFMX_RANSAC_HYP=legacy) produce the same hypotheses, conditioning estimates, flags and counts, bit for bit."""
+    xi, xj = golden["tv_xi"], golden["tv_xj"]
+    idx8 = H.uniform_draws(O, "orc", 777, len(xi), 8 * 2500).reshape(2500, 8)
+    out = {}
+    for var in ("legacy", "lean"):
+        monkeypatch.setenv("SFMX_RANSAC_HYP", var)
+        out[var] = ctx.ransac_score_ex(xi, xj, idx8, 1e-3)
+    for k in ("E", "cond", "flags", "counts", "lo", "hi"):
+        H.assert_bits_equal(np.ascontiguousarray(out["lean"][k]), np.ascontiguousarray(out["legacy"][k]), k)
+    assert (out["lean"]["best_iter"], out["lean"]["best_count"]) == (out["legacy"]["best_iter"], out["legacy"]["best_count"])
+
+
 def test_klt_empty_and_radius_limits(ctx, golden):
     pa, pb = ctx.pyramid(golden["klt_a"], 3), ctx.pyramid(golden["klt_b"], 3)
     fwd, back, keep, steps = ctx.klt_track(pa, pb, np.zeros((0, 2)))
