@@ -1,1 +1,3 @@
-python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "matrix_core or sum_schedules or loop_variants" > gpurun_out/r03_aa_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r03_aa_tests.log
+python -m pytest tests -m gpu -x -q > gpurun_out/r03_final_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03_final_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03_final_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/r03_final_smoke.log
+python bench.py > gpurun_out/r03_final_bench.json 2> gpurun_out/r03_final_bench.err
