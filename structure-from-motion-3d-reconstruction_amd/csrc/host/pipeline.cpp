@@ -996,8 +996,8 @@ static std::chrono::microseconds spin_window() {
   return std::chrono::microseconds(us);
 }
 template <class Pred>
-static bool spin_until(Pred&& ready) {
-  const auto win = spin_window();
+static bool spin_until(Pred&& ready, int own_us = -1) {
+  const auto win = own_us >= 0 ? std::chrono::microseconds(own_us) : spin_window();
   if (win.count() == 0) return ready();
   const auto t0 = Clock::now();
   for (int i = 0;; ++i) {
@@ -1016,7 +1016,7 @@ void AsyncLane::submit(std::function<void()> task) {
 }
 void AsyncLane::wait() {
   const std::uint64_t want = submitted_.load(std::memory_order_acquire);
-  (void)spin_until([&] { return completed_.load(std::memory_order_acquire) >= want; });
+  (void)spin_until([&] { return completed_.load(std::memory_order_acquire) >= want; }, spin_us_.load(std::memory_order_relaxed));
   std::unique_lock<std::mutex> lk(mu_);
   cv_idle_.wait(lk, [&] { return queue_.empty() && !busy_; });
   if (error_) {
@@ -1030,7 +1030,7 @@ void AsyncLane::run() {
   std::uint64_t taken = 0;
   for (;;) {
     std::function<void()> task;
-    (void)spin_until([&] { return submitted_.load(std::memory_order_acquire) > taken; });
+    (void)spin_until([&] { return submitted_.load(std::memory_order_acquire) > taken; }, spin_us_.load(std::memory_order_relaxed));
     {
       std::unique_lock<std::mutex> lk(mu_);
       cv_task_.wait(lk, [&] { return stop_ || !queue_.empty(); });
@@ -1476,6 +1476,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   std::unique_ptr<AsyncLane> lane, lane_c, lane_e;
   if (use_lane) {
     lane = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_B", 0), ContextPool::LANE_B);
+    // SFMX_SPIN_B_US: polling window of the ONE hand-off pair on the pass's critical chain -- the geometry thread waiting for BA(k)
+    // and lane B waiting for the next job (twice per keyframe; every other lane keeps sleeping at once)
+    if (const char* sb = std::getenv("SFMX_SPIN_B_US")) lane->set_spin_us(std::max(0, std::atoi(sb)));
     lane_c = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_C", 0), ContextPool::LANE_C);
     if (!std::getenv("SFMX_NO_EDGE_LANE"))
       lane_e = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_E", 0), ContextPool::LANE_E);

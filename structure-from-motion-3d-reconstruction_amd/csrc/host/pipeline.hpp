@@ -452,9 +452,12 @@ class AsyncLane {
   void submit(std::function<void()> task);
   void wait();
   double busy_seconds() const { return busy_seconds_; }  // time spent inside tasks (read while idle)
+  // this lane's own polling window before it (and whoever waits for it) sleeps; -1 = the process-wide SFMX_SPIN_US
+  void set_spin_us(int us) { spin_us_.store(us, std::memory_order_relaxed); }
 
  private:
   void run();
+  std::atomic<int> spin_us_{-1};
   double busy_seconds_ = 0;
   PooledCtx* pc_ = nullptr;
   sfmx_ctx* ctx_ = nullptr;
