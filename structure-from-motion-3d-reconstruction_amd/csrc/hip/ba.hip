@@ -23,8 +23,56 @@
 #include "sfmx_internal.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <vector>
+
+// ---- diagnostic build only (make HIPFLAGS_EXTRA=-DSFMX_BA_WGSTAMPS): every workgroup of the two window kernels appends
+// {start, end (s_memrealtime, 100 MHz), hardware id, kind | block | grid} to a device ring, sfmx_debug_dump_wgstamps(path) writes
+// it out -- where the 3x stretch of these kernels inside the pipeline comes from (tools/ba_wgstamps.py).  No code in the product build.
+#ifdef SFMX_BA_WGSTAMPS
+#define WGS_CAP (1u << 20)
+__device__ unsigned long long g_wgs_ring[WGS_CAP][4];
+__device__ unsigned g_wgs_next;
+struct WgStamp {
+  unsigned long long t0;
+  unsigned hw;
+  __device__ __forceinline__ WgStamp() {
+    t0 = __builtin_amdgcn_s_memrealtime();
+    hw = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 28);  // HW_ID | XCC_ID << 28
+  }
+  __device__ __forceinline__ void done(int kind, int blk, int nblk) const {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned slot = atomicAdd(&g_wgs_next, 1u) & (WGS_CAP - 1);
+      g_wgs_ring[slot][0] = t0;
+      g_wgs_ring[slot][1] = __builtin_amdgcn_s_memrealtime();
+      g_wgs_ring[slot][2] = hw;
+      g_wgs_ring[slot][3] = ((unsigned long long)kind << 48) | ((unsigned long long)(unsigned)blk << 24) | (unsigned)nblk;
+    }
+  }
+};
+extern "C" int sfmx_debug_dump_wgstamps(const char* path) {
+  unsigned n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgs_next), 4) != hipSuccess) return -1;
+  const unsigned cnt = n < WGS_CAP ? n : WGS_CAP;
+  std::vector<unsigned long long> h((size_t)cnt * 4);
+  if (cnt && hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wgs_ring), (size_t)cnt * 32) != hipSuccess) return -1;
+  FILE* f = fopen(path, "wb");
+  if (!f) return -1;
+  fwrite(h.data(), 32, cnt, f);
+  fclose(f);
+  n = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgs_next), &n, 4);
+  return (int)cnt;
+}
+#define WGS_BEGIN WgStamp wgs_
+#define WGS_END(kind, blk, nblk) wgs_.done(kind, blk, nblk)
+#else
+#define WGS_BEGIN
+#define WGS_END(kind, blk, nblk)
+#endif
 
 #define BA_SLOT 84  // doubles per (point, pose) slot: Hxx 36 | bx 6 | Hxp 18 | G 18 | G*bp 6
 #define BA_MAX_OBS 16
@@ -48,6 +96,7 @@ struct sfmx_ba_problem {
   unsigned* ticket = nullptr;  // finished-workgroup counter of the fused reduce + solve (zero between launches)
   hipEvent_t ev_sync = nullptr, ev_exp[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};  // chunked expand / reduce pipeline
   int chunk = 0;                // points per chunk of the contribution-row ring (0: all rows resident)
+  bool lds_points = false;      // window shape without a point that one pose observes twice: k_ba_points_window_lds
   // resident job (k_ba_window_resident): launched by sfmx_ba_begin, fed by sfmx_ba_step, released by sfmx_ba_end
   bool job_active = false;
   int job_iters = 0, job_done = 0;
@@ -384,9 +433,140 @@ __device__ __forceinline__ void ba_points_body(int W, int P, int MS, const doubl
 // each, one or two per SIMD) a 200-VGPR wave often finds none -- every launch slower than 60 us in the kernel trace
 // overlapped a KLT launch.  In the pipeline 37 -> 26 us per launch (9.5 us alone either way).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ba_points_window(BA_POINTS_PARAMS) {
+  WGS_BEGIN;
   ba_points_body<BA_PTS, 256>(BA_POINTS_PASS);
+  WGS_END(1, (int)blockIdx.x, (int)gridDim.x);
 }
 __global__ __launch_bounds__(64) void k_ba_points_bulk(BA_POINTS_PARAMS) { ba_points_body<64, 64>(BA_POINTS_PASS); }
+
+// The window shape with everything a workgroup touches between its inputs and its contribution rows in LDS: the observation
+// lists, the slot tables and the slot records of its BA_PTS points.  k_ba_points_window keeps the records and the slot tables in
+// global memory (they are an output of the bulk shape, which the expansion kernel reads back); for a window the merged expansion
+// is their only reader, and by workgroup timestamps (tools/ba_wgstamps.py) a workgroup of that kernel spends 19.6 us -- with the
+// device to itself -- almost entirely in L2 round trips: the serial slot assignment (a load per observation, and a load after a
+// store on the slot table), the record stores / loads around the gain, and two dependent loads per row entry in the expansion.
+// Same arithmetic, same order: ba_observation / the ordered Hpp | bp sums / inv3_ref / ba_slot_gain, unchanged.
+// Precondition (checked on the host when the problem is set up): no pose observes a point twice (that case is a read-modify-write
+// of the slot record, which stays with the general kernel); points with more than BA_MAX_OBS observations contribute nothing
+// (T:915-918).  WT: window size as a compile-time constant (0 = read W), so that the row-entry decoding divides by constants.
+template <int WT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ba_points_window_lds(BA_POINTS_PARAMS) {
+  WGS_BEGIN;
+  constexpr int PTS = BA_PTS;
+  extern __shared__ __align__(16) double s_rec[];  // [PTS][MS][BA_SLOT]
+  __shared__ double sp[BA_MAX_W * 12];
+  __shared__ double s_term[PTS][BA_MAX_OBS][12];
+  __shared__ double s_H[PTS][12], s_iH[PTS][9];
+  __shared__ int s_n[PTS], s_na[PTS], s_ok[PTS], s_o0[PTS];
+  __shared__ int s_li[PTS][BA_MAX_OBS];
+  __shared__ int8_t s_slot[PTS][BA_MAX_OBS], s_adds[PTS][BA_MAX_OBS], s_so[PTS][BA_MAX_W];
+  if (wave_prio) __builtin_amdgcn_s_setprio(3);
+  const int Wc = WT ? WT : W;
+  const int tid = threadIdx.x, p0 = (int)blockIdx.x * PTS;
+  const int pt = tid / BA_MAX_OBS, k = tid % BA_MAX_OBS;
+  // ---- inputs: poses, the observation lists of the points (one lane per observation), empty slot tables
+  for (int i = tid; i < Wc * 12; i += 256) sp[i] = poses[i];
+  for (int i = tid; i < PTS * Wc; i += 256) s_so[i / Wc][i % Wc] = -1;
+  if (tid < PTS * BA_MAX_OBS) {
+    const int p = p0 + pt;
+    int o0 = 0, cnt = 0;
+    if (p < P) {
+      o0 = obs_ptr[p];
+      cnt = obs_ptr[p + 1] - o0;
+    }
+    if (cnt > BA_MAX_OBS) cnt = 0;  // T:915-918: the point is skipped as a whole
+    if (k == 0) { s_o0[pt] = o0; s_n[pt] = cnt; }
+    s_li[pt][k] = k < cnt ? obs_li[o0 + k] : -1;
+  }
+  __syncthreads();
+  // ---- slots in first-observation order (T:925-930): integer work on LDS, one lane per point
+  if (tid < PTS) {
+    const int n = s_n[tid];
+    int na = 0;
+    for (int kk = 0; kk < n; kk++) {
+      const int li = s_li[tid][kk];
+      int sl = -1;
+      if (li >= 0 && li < Wc) {  // (malformed pose index: ignored, as in the general kernel)
+        sl = na++;               // precondition: this pose has no slot yet
+        s_so[tid][li] = (int8_t)sl;
+      }
+      s_slot[tid][kk] = (int8_t)sl;
+    }
+    s_na[tid] = na;
+  }
+  __syncthreads();
+  // ---- one lane per observation: the slot record (Hxx | bx | Hxp) and the twelve terms of Hpp | bp
+  if (tid < PTS * BA_MAX_OBS && k < s_n[pt]) {
+    const int p = p0 + pt, sl = s_slot[pt][k];
+    bool adds = false;
+    if (sl >= 0) {
+      const int o = s_o0[pt] + k;
+      adds = ba_observation<true>(s_rec + ((size_t)pt * MS + sl) * BA_SLOT, sp + 12 * s_li[pt][k], X[3 * p], X[3 * p + 1], X[3 * p + 2], obs_uv[2 * o],
+                                  obs_uv[2 * o + 1], fx, fy, cx, cy, huber, s_term[pt][k]);
+    }
+    s_adds[pt][k] = adds ? 1 : 0;
+  }
+  __syncthreads();
+  if (tid < PTS * 12) {  // ---- Hpp (9) and bp (3): the reference's += chain over the observations
+    const int q = tid / 12, e = tid % 12, n = s_n[q];
+    double acc = 0.0;
+    for (int kk = 0; kk < n; kk++)
+      if (s_adds[q][kk]) acc += s_term[q][kk][e];
+    s_H[q][e] = acc;
+  }
+  __syncthreads();
+  if (tid < PTS) {
+    int ok = 0;
+    if (p0 + tid < P && s_n[tid] > 0) ok = inv3_ref(s_H[tid], s_iH[tid]) ? 1 : 0;
+    if (!ok)  // T:1012 (or no usable observation): the point contributes nothing at all
+      for (int i = 0; i < Wc; i++) s_so[tid][i] = -1;
+    s_ok[tid] = ok;
+  }
+  __syncthreads();
+  if (tid < PTS * BA_MAX_OBS && s_ok[pt] && k < s_na[pt])  // ---- one lane per slot: G = Hxp Hpp^-1, G*bp
+    ba_slot_gain(s_rec + ((size_t)pt * MS + k) * BA_SLOT, s_iH[pt], s_H[pt] + 9);
+  __syncthreads();
+  // ---- contribution rows (layout: see ba_points_body), every operand from LDS
+  const int D = 6 * Wc, CS = ba_row_stride(Wc);
+  const int np = min(PTS, P - p0);
+  for (int e = tid; e < CS; e += 256) {
+    int pa, pb = -1, off_a, off_b = 0;
+    if (e < D * D) {
+      const int i = e / D, j = e % D;
+      pa = i / 6; pb = j / 6;
+      off_a = 60 + (i % 6) * 3; off_b = 42 + (j % 6) * 3;
+    } else if (e < D * D + 36 * Wc) {
+      const int kk = e - D * D;
+      pa = kk / 36; off_a = kk % 36;
+    } else if (e < D * D + 36 * Wc + D) {
+      const int i = e - (D * D + 36 * Wc);
+      pa = i / 6; off_a = 36 + (i % 6);
+    } else {
+      const int i = e - (D * D + 36 * Wc + D);
+      pa = i / 6; off_a = 78 + (i % 6);
+    }
+#pragma unroll
+    for (int pl = 0; pl < PTS; pl++) {
+      if (pl < np) {
+        const double* base = s_rec + (size_t)pl * MS * BA_SLOT;
+        const int sa = s_so[pl][pa];
+        double v = 0.0;
+        if (pb >= 0) {
+          const int sb = s_so[pl][pb];
+          if (sa >= 0 && sb >= 0) {
+            const double* g = base + (size_t)sa * BA_SLOT + off_a;
+            const double* h = base + (size_t)sb * BA_SLOT + off_b;
+            v = g[0] * h[0] + g[1] * h[1] + g[2] * h[2];
+          }
+        } else if (sa >= 0) {
+          v = base[(size_t)sa * BA_SLOT + off_a];
+        }
+        C[(size_t)(p0 + pl) * CS + e] = v;
+      }
+    }
+  }
+  WGS_END(1, (int)blockIdx.x, (int)gridDim.x);
+}
 #undef BA_POINTS_PARAMS
 #undef BA_POINTS_PASS
 
@@ -950,8 +1130,13 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
                                                    unsigned long long seq, int wave_prio, const double* init = nullptr, int wg_off = 0,
                                                    int publish_system = 0) {
   // wg_off: element-sharded launches cover a slice of the element blocks
+  WGS_BEGIN;
   ba_reduce_body<BAR_TP, SOLVE_N, BAR_NPF, BAR_NBUF>(W, P, C, lambda, damp, S, b, ticket, work, host_out, seq, wave_prio, init,
                                                      (int)blockIdx.x + wg_off, (int)gridDim.x, publish_system);
+#ifdef SFMX_BA_WGSTAMPS
+  // (the body returns early in all workgroups but the last of a fused launch: stamped here only when it falls through)
+#endif
+  WGS_END(2, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------ resident window BA
@@ -1419,7 +1604,19 @@ static int ba_chunk_points() {
 // points phase of one iteration: the records of every point (and, in the merged shape, their contribution rows)
 static int ba_launch_points(sfmx_ctx* c, sfmx_ba_problem* q, const double* d_poses, double fx, double fy, double cx, double cy, double huber,
                             int wave_prio) {
-  if (ba_merged(q)) {
+  // SFMX_BA_POINTS=global: the window kernel with its records in global memory (A/B and tests; identical rows)
+  const char* pts_env = getenv("SFMX_BA_POINTS");
+  const size_t rec_lds = (size_t)BA_PTS * q->MS * BA_SLOT * 8;
+  if (ba_merged(q) && q->lds_points && rec_lds <= 40960 && !(pts_env && pts_env[0] == 'g')) {
+    const int nwg = (q->P + BA_PTS - 1) / BA_PTS;
+    if (q->W == 6) {
+      SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window_lds<6><<<nwg, 256, rec_lds, c->stream>>>(
+                                      q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
+    } else {
+      SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window_lds<0><<<nwg, 256, rec_lds, c->stream>>>(
+                                      q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
+    }
+  } else if (ba_merged(q)) {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window<<<(q->P + BA_PTS - 1) / BA_PTS, 256, 0, c->stream>>>(
                                     q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
   } else {
@@ -1433,7 +1630,13 @@ static int ba_element_blocks(const sfmx_ba_problem* q) { const int D = 6 * q->W;
 static void ba_reduce_kernel(sfmx_ctx* c, sfmx_ba_problem* q, const double* rows, int p_cnt, double lambda, int damp, double* S_out, double* b_out,
                              const double* init, bool fused_solve, double* host_out, unsigned long long seq, int wave_prio, int wg_lo, int nwg,
                              int publish_system, bool streaming) {
-  if (fused_solve && q->W == 6) {
+  // SFMX_BA_TILE=32: 32-row tiles with a four-tile register ring for the window shape -- 16 KB of LDS per workgroup instead of 33
+  // (a workgroup then fits next to six resident KLT waves of a CU instead of five); A/B switch, identical sums
+  const char* tile_env = getenv("SFMX_BA_TILE");
+  if (fused_solve && q->W == 6 && tile_env && atoi(tile_env) == 32) {
+    k_ba_reduce<32, 36, 4, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, q->ticket, q->work, host_out, seq, wave_prio, init,
+                                                         wg_lo, publish_system);
+  } else if (fused_solve && q->W == 6) {
     k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, q->ticket, q->work, host_out, seq, wave_prio, init,
                                                          wg_lo, publish_system);
   } else if (fused_solve && q->W == 10) {
@@ -1624,6 +1827,23 @@ int sfmx_ba_reset(sfmx_ctx* c, sfmx_ba_problem* q, int W, int P, const double* X
   q->poses = q->bufs[4].as<double>(); q->rec = q->bufs[5].as<double>();
   q->slot_of = q->bufs[6].as<int8_t>(); q->S = q->bufs[7].as<double>(); q->b = q->S + (size_t)D * D;  // S | b contiguous: one all-reduce
   q->work = q->bufs[9].as<double>();
+  // does any pose observe a point twice?  (the LDS points kernel leaves that read-modify-write case to the general one)
+  q->lds_points = false;
+  if (ba_merged(q)) {
+    bool dup = false;
+    for (int p = 0; p < P && !dup; p++) {
+      const int o0 = obs_ptr[p], cnt = obs_ptr[p + 1] - o0;
+      if (cnt < 2 || cnt > BA_MAX_OBS) continue;
+      unsigned long long seen = 0;  // W <= 64
+      for (int k = 0; k < cnt; k++) {
+        const int li = obs_li[o0 + k];
+        if (li < 0 || li >= W) continue;
+        if (seen >> li & 1ull) { dup = true; break; }
+        seen |= 1ull << li;
+      }
+    }
+    q->lds_points = !dup;
+  }
   if (c->ba_upload_in_flight) {  // two resets in a row: the staging slab is still being read
     SFMX_HIP(c, hipStreamSynchronize(c->stream));
     c->ba_upload_in_flight = false;

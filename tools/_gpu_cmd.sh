@@ -1,1 +1,3 @@
-python tools/ab_inproc.py --reps 30 --passes 3 "base:" "spinB30:SFMX_SPIN_B_US=30" "spinB100:SFMX_SPIN_B_US=100" "spinB400:SFMX_SPIN_B_US=400" "spinB2000:SFMX_SPIN_B_US=2000" > gpurun_out/r03_ab_inproc_spin.txt 2>&1
+python -m pytest tests -x -q -m gpu -k "ba_ or bench_workload or e2e or pipeline_vs or async_lanes" > gpurun_out/r03_ae_tests.log 2>&1; echo "rc=$?" >> gpurun_out/r03_ae_tests.log
+timeout -k 10 400 python tools/ba_wgstamps.py > gpurun_out/r03_ba_wgstamps2.txt 2>&1
+python tools/ab_inproc.py --reps 30 --passes 3 "points-global:SFMX_BA_POINTS=global" "points-lds:" > gpurun_out/r03_ab_inproc_points.txt 2>&1
