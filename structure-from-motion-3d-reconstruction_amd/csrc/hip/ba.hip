@@ -33,11 +33,12 @@
 // it out -- where the 3x stretch of these kernels inside the pipeline comes from (tools/ba_wgstamps.py).  No code in the product build.
 #ifdef SFMX_BA_WGSTAMPS
 #define WGS_CAP (1u << 20)
-__device__ unsigned long long g_wgs_ring[WGS_CAP][4];
+__device__ unsigned long long g_wgs_ring[WGS_CAP][8];
 __device__ unsigned g_wgs_next;
 struct WgStamp {
-  unsigned long long t0;
+  unsigned long long t0, m[4] = {0, 0, 0, 0};
   unsigned hw;
+  __device__ __forceinline__ void mark(int i) { m[i] = __builtin_amdgcn_s_memrealtime(); }
   __device__ __forceinline__ WgStamp() {
     t0 = __builtin_amdgcn_s_memrealtime();
     hw = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 28);  // HW_ID | XCC_ID << 28
@@ -50,6 +51,7 @@ struct WgStamp {
       g_wgs_ring[slot][1] = __builtin_amdgcn_s_memrealtime();
       g_wgs_ring[slot][2] = hw;
       g_wgs_ring[slot][3] = ((unsigned long long)kind << 48) | ((unsigned long long)(unsigned)blk << 24) | (unsigned)nblk;
+      for (int i = 0; i < 4; i++) g_wgs_ring[slot][4 + i] = m[i];
     }
   }
 };
@@ -57,11 +59,11 @@ extern "C" int sfmx_debug_dump_wgstamps(const char* path) {
   unsigned n = 0;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgs_next), 4) != hipSuccess) return -1;
   const unsigned cnt = n < WGS_CAP ? n : WGS_CAP;
-  std::vector<unsigned long long> h((size_t)cnt * 4);
-  if (cnt && hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wgs_ring), (size_t)cnt * 32) != hipSuccess) return -1;
+  std::vector<unsigned long long> h((size_t)cnt * 8);
+  if (cnt && hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_wgs_ring), (size_t)cnt * 64) != hipSuccess) return -1;
   FILE* f = fopen(path, "wb");
   if (!f) return -1;
-  fwrite(h.data(), 32, cnt, f);
+  fwrite(h.data(), 64, cnt, f);
   fclose(f);
   n = 0;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgs_next), &n, 4);
@@ -69,9 +71,15 @@ extern "C" int sfmx_debug_dump_wgstamps(const char* path) {
 }
 #define WGS_BEGIN WgStamp wgs_
 #define WGS_END(kind, blk, nblk) wgs_.done(kind, blk, nblk)
+#define WGS_MARK(i) wgs_.mark(i)
+#define WGS_PARAM , WgStamp& wgs_
+#define WGS_ARG , wgs_
 #else
 #define WGS_BEGIN
 #define WGS_END(kind, blk, nblk)
+#define WGS_MARK(i)
+#define WGS_PARAM
+#define WGS_ARG
 #endif
 
 #define BA_SLOT 84  // doubles per (point, pose) slot: Hxx 36 | bx 6 | Hxp 18 | G 18 | G*bp 6
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     s_li[pt][k] = k < cnt ? obs_li[o0 + k] : -1;
   }
   __syncthreads();
+  WGS_MARK(0);  // inputs staged
   // ---- slots in first-observation order (T:925-930): integer work on LDS, one lane per point
   if (tid < PTS) {
     const int n = s_n[tid];
@@ -507,6 +516,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     s_adds[pt][k] = adds ? 1 : 0;
   }
   __syncthreads();
+  WGS_MARK(1);  // observations
   if (tid < PTS * 12) {  // ---- Hpp (9) and bp (3): the reference's += chain over the observations
     const int q = tid / 12, e = tid % 12, n = s_n[q];
     double acc = 0.0;
@@ -526,6 +536,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   if (tid < PTS * BA_MAX_OBS && s_ok[pt] && k < s_na[pt])  // ---- one lane per slot: G = Hxp Hpp^-1, G*bp
     ba_slot_gain(s_rec + ((size_t)pt * MS + k) * BA_SLOT, s_iH[pt], s_H[pt] + 9);
   __syncthreads();
+  WGS_MARK(2);  // sums, inverse, gain
   // ---- contribution rows (layout: see ba_points_body), every operand from LDS
   const int D = 6 * Wc, CS = ba_row_stride(Wc);
   const int np = min(PTS, P - p0);
@@ -545,26 +556,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       const int i = e - (D * D + 36 * Wc + D);
       pa = i / 6; off_a = 78 + (i % 6);
     }
+    // branch-free and batched over the workgroup's points: all slot lookups, then all record reads (a missing slot reads slot 0,
+    // a valid address, and is masked out afterwards), then the arithmetic and the stores -- two LDS round trips per row entry
+    // instead of up to three per point (the lanes of a wave hold different entries and points with different slot tables, so every
+    // branch of the straightforward form was taken by somebody)
+    const bool schur = pb >= 0;
+    int sa[PTS], sb[PTS];
 #pragma unroll
     for (int pl = 0; pl < PTS; pl++) {
-      if (pl < np) {
-        const double* base = s_rec + (size_t)pl * MS * BA_SLOT;
-        const int sa = s_so[pl][pa];
-        double v = 0.0;
-        if (pb >= 0) {
-          const int sb = s_so[pl][pb];
-          if (sa >= 0 && sb >= 0) {
-            const double* g = base + (size_t)sa * BA_SLOT + off_a;
-            const double* h = base + (size_t)sb * BA_SLOT + off_b;
-            v = g[0] * h[0] + g[1] * h[1] + g[2] * h[2];
-          }
-        } else if (sa >= 0) {
-          v = base[(size_t)sa * BA_SLOT + off_a];
-        }
-        C[(size_t)(p0 + pl) * CS + e] = v;
-      }
+      sa[pl] = s_so[pl][pa];
+      sb[pl] = schur ? s_so[pl][pb] : 0;
+    }
+    double g0[PTS], g1[PTS], g2[PTS], h0[PTS], h1[PTS], h2[PTS];
+#pragma unroll
+    for (int pl = 0; pl < PTS; pl++) {
+      const double* base = s_rec + (size_t)pl * MS * BA_SLOT;
+      const double* g = base + (size_t)(sa[pl] >= 0 ? sa[pl] : 0) * BA_SLOT + off_a;
+      const double* h = base + (size_t)(sb[pl] >= 0 ? sb[pl] : 0) * BA_SLOT + off_b;
+      // (unconditional reads: for a one-operand entry the extra five values are read and never used; the dynamic allocation is
+      // two doubles longer than the records so that even the last slot's G*bp entry reads inside it)
+      g0[pl] = g[0]; g1[pl] = g[1]; g2[pl] = g[2];
+      h0[pl] = h[0]; h1[pl] = h[1]; h2[pl] = h[2];
+    }
+#pragma unroll
+    for (int pl = 0; pl < PTS; pl++) {
+      const double dot = g0[pl] * h0[pl] + g1[pl] * h1[pl] + g2[pl] * h2[pl];
+      const bool have = schur ? (sa[pl] >= 0 && sb[pl] >= 0) : sa[pl] >= 0;
+      const double v = have ? (schur ? dot : g0[pl]) : 0.0;
+      if (pl < np) C[(size_t)(p0 + pl) * CS + e] = v;
     }
   }
+  WGS_MARK(3);  // rows issued
   WGS_END(1, (int)blockIdx.x, (int)gridDim.x);
 }
 #undef BA_POINTS_PARAMS
@@ -953,7 +975,7 @@ template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
 __device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
                                                double* __restrict__ b, unsigned* __restrict__ ticket, double* __restrict__ work,
                                                double* __restrict__ host_out, unsigned long long seq, int wave_prio, const double* init,
-                                               int blk, int nblk, int publish_system) {
+                                               int blk, int nblk, int publish_system WGS_PARAM) {
   // blk / nblk: this workgroup's element block and how many blocks the launch has (the ticket of the fused solve counts them)
   // init (optional, [D*D + D] in S | b layout, may alias S): the chains start from these values instead of +0.0 -- a shard
   // that continues the running sums of the shard before it (relay mode: the reference's sequence across shards)
@@ -1004,6 +1026,7 @@ __device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __res
 #pragma unroll
   for (int j = 0; j < BAR_NPF; j++)
     if (j < ntiles) load_tile(j, rv[j], ru[j]);
+  WGS_MARK(0);  // indices, first loads issued
   for (int t0 = 0; t0 < ntiles; t0 += BAR_NPF) {
 #pragma unroll
     for (int j = 0; j < BAR_NPF; j++) {
@@ -1073,6 +1096,7 @@ __device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __res
       }
     }
   }
+  WGS_MARK(1);  // chains done
   __syncthreads();  // the LDS tiles are reused by the solve below
   if (tid < BAR_COLS && valid) {
     if (is_b) {
@@ -1087,12 +1111,34 @@ __device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __res
     }
   }
   if constexpr (SOLVE_N > 0) {
-    // ---- the last workgroup to get here solves the system the others have just finished writing
     __shared__ int is_last;
+    if (publish_system == 2) {
+      // The host solves (csrc/hip/solve_host.cpp) and every workgroup hands ITS 16 elements of S | b to the pinned block itself
+      // (one 128-byte write), made visible system-wide before its ticket; the workgroup that takes the last ticket only writes the
+      // sequence word the host polls.  (publish_system == 1: the last workgroup copies all of S | b, 10 KB at 36 unknowns, after the
+      // others are done -- 5 us at the end of the launch by workgroup timestamps.)
+      if (tid < BAR_COLS && valid) {
+        host_out[e] = acc;
+        __threadfence_system();
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const bool last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nblk - 1u;
+        if (last) {
+          __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch on this stream
+          __threadfence_system();
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + (SOLVE_N * SOLVE_N + SOLVE_N)), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      WGS_MARK(2);
+      return;
+    }
+    // ---- the last workgroup to get here solves the system the others have just finished writing
     if (tid < BAR_COLS) __threadfence();  // this workgroup's elements are visible device-wide before its ticket is
     __syncthreads();
     if (tid == 0) is_last = atomicAdd(ticket, 1u) == (unsigned)nblk - 1u ? 1 : 0;
     __syncthreads();
+    WGS_MARK(2);  // elements stored, ticket taken
     if (!is_last) return;
     __threadfence();  // acquire: S | b of every other workgroup
     if (tid == 0) *ticket = 0;  // for the next launch on this stream
@@ -1132,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
   // wg_off: element-sharded launches cover a slice of the element blocks
   WGS_BEGIN;
   ba_reduce_body<BAR_TP, SOLVE_N, BAR_NPF, BAR_NBUF>(W, P, C, lambda, damp, S, b, ticket, work, host_out, seq, wave_prio, init,
-                                                     (int)blockIdx.x + wg_off, (int)gridDim.x, publish_system);
+                                                     (int)blockIdx.x + wg_off, (int)gridDim.x, publish_system WGS_ARG);
 #ifdef SFMX_BA_WGSTAMPS
   // (the body returns early in all workgroups but the last of a fused launch: stamped here only when it falls through)
 #endif
@@ -1166,6 +1212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int wave_prio, int n_elem_blocks) {
   // n_elem_blocks <= gridDim.x: the first n_elem_blocks workgroups reduce one block of 16 elements each; all of them take part in
   // the points phase and in the barriers
+  WGS_BEGIN;
   __shared__ unsigned long long s_cmd;
   __shared__ int s_flag;
   __shared__ double s_poses[BA_MAX_W * 12];
@@ -1212,7 +1259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (!s_flag) return;
     __threadfence();
     // ---- reduction of this workgroup's element block over all points (damping and gauge included, T:1064-1071)
-    if (blk < n_elem_blocks) ba_reduce_body<64, 0, 2, 2>(W, P, C, lambda, 1, S, b, nullptr, nullptr, nullptr, 0, wave_prio, nullptr, blk, n_elem_blocks, 0);
+    if (blk < n_elem_blocks) ba_reduce_body<64, 0, 2, 2>(W, P, C, lambda, 1, S, b, nullptr, nullptr, nullptr, 0, wave_prio, nullptr, blk, n_elem_blocks, 0 WGS_ARG);
     // ---- the last workgroup to finish hands S | b to the host
     __threadfence();
     __syncthreads();
@@ -1606,7 +1653,7 @@ static int ba_launch_points(sfmx_ctx* c, sfmx_ba_problem* q, const double* d_pos
                             int wave_prio) {
   // SFMX_BA_POINTS=global: the window kernel with its records in global memory (A/B and tests; identical rows)
   const char* pts_env = getenv("SFMX_BA_POINTS");
-  const size_t rec_lds = (size_t)BA_PTS * q->MS * BA_SLOT * 8;
+  const size_t rec_lds = (size_t)BA_PTS * q->MS * BA_SLOT * 8 + 16;
   if (ba_merged(q) && q->lds_points && rec_lds <= 40960 && !(pts_env && pts_env[0] == 'g')) {
     const int nwg = (q->P + BA_PTS - 1) / BA_PTS;
     if (q->W == 6) {
@@ -2016,7 +2063,11 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(host_solve ? hout + NE : hout + D + 1);
   const unsigned long long seq = ++c->ba_seq;
   if (poll) *flag = 0;  // (a freshly grown buffer holds arbitrary bytes)
-  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t, poll, fuse, poll ? hout : nullptr, seq, host_solve ? 1 : 0);
+  // SFMX_BA_PUBLISH=last: S | b copied to the pinned block by the last workgroup of the reduction (A/B and tests) instead of by every
+  // workgroup for its own elements
+  const char* pub_env = getenv("SFMX_BA_PUBLISH");
+  const int publish_mode = (pub_env && pub_env[0] == 'l') ? 1 : 2;
+  int rc = ba_launch_build(c, q, poses_wc, fx, fy, cx, cy, huber, lambda, 1, t, poll, fuse, poll ? hout : nullptr, seq, host_solve ? publish_mode : 0);
   if (rc) return rc;
   if (!fuse) {
     int* dstatus = reinterpret_cast<int*>(q->work + D);

@@ -1655,8 +1655,18 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     if (make_kf) {
       // Edges stay in keyframe order (lane C first).  BA(k-1) refined the poses the triangulation below reads, but
       // nothing before it does: unless a loop closure has to be finished first, lane B is joined as late as that.
-      const bool looped = join_c();
-      if (looped) { join_b(); finish_loop(); }
+      // The verdict of the last keyframe's loop verification (lane C: KLT + RANSAC, ~260 us) is what the geometry thread waited
+      // for longest per keyframe; everything that neither the verdict nor finish_loop() can change runs BEFORE the join now:
+      // this keyframe's observation table and track histories, the correspondences of its sequential edge, the walk that
+      // collects the triangulation jobs.  What finish_loop() reads or orders -- the map's observation lists (its BA gathers
+      // from them) and the list of pending edges (the loop edge goes in front of this keyframe's sequential edge) -- is touched
+      // only after the join.  SFMX_JOIN_C_EARLY=1: the join first, as before (A/B and tests; identical output).
+      const bool late_join = std::getenv("SFMX_JOIN_C_EARLY") == nullptr;
+      bool looped = false;
+      if (!late_join) {
+        looped = join_c();
+        if (looped) { join_b(); finish_loop(); }
+      }
       Keyframe kf(arena);
       kf.kf_id = (int)kfs.size();
       kf.frame_idx = fi;
@@ -1665,15 +1675,22 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       const std::vector<float>& new_desc = pkt.desc;
       keep_corners(fi, pkt.corners);
       const auto tb0 = Clock::now();
+      std::vector<std::pair<int, V2>> late_obs;  // observations of already mapped tracks: into the map after the join
+      if (late_join) late_obs.reserve(pkt.tracks.size());
       for (const Track& tr : pkt.tracks) {
         kf.obs.emplace(tr.id, tr.p);
         TrackHist& th = track_hist.try_emplace(tr.id, arena).first->second;
         th.obs.push_back({kf.kf_id, tr.p});
-        if (th.mapped) map.add_obs(tr.id, kf.kf_id, tr.p);
+        if (th.mapped) {
+          if (late_join) late_obs.emplace_back(tr.id, tr.p);
+          else map.add_obs(tr.id, kf.kf_id, tr.p);
+        }
       }
-      if (!kfs.empty()) {  // sequential pose-graph edge (T:1782-1798)
+      std::vector<V2> ei, ej;
+      int edge_prev_id = -1;
+      if (!kfs.empty()) {  // sequential pose-graph edge (T:1782-1798): its correspondences
         const Keyframe& prev_kf = kfs.back();
-        std::vector<V2> ei, ej;
+        edge_prev_id = prev_kf.kf_id;
         ei.reserve(1200);
         ej.reserve(1200);
         for (const auto& kv : kf.obs) {
@@ -1682,23 +1699,14 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           ei.push_back(itp->second);
           ej.push_back(kv.second);
         }
-        clk.bookkeeping += since(tb0);
-        if (ei.size() >= 80) {
-          pending_edges.push_back(PendingEdge{prev_kf.kf_id, kf.kf_id, nullptr});
-          PendingEdge* slot = &pending_edges.back();  // std::deque: stays valid while later edges are appended
-          auto task = [slot, ectx, eclk, K, ransac_ahead, ei = std::move(ei), ej = std::move(ej)]() {
-            slot->ra = ransac_ahead(ectx, K, ei, ej, 2500, 1e-3, 60, eclk);
-          };
-          if (edge_lane) edge_lane->submit(std::move(task));
-          else task();
-        }
       }
-      if (kfs.size() >= 1) {  // triangulate new points (T:1801-1813)
-        const auto th0 = Clock::now();
-        // The DLT solves (libm Jacobi) are independent: gather the jobs in the reference's iteration
-        // order, solve them on the host pool, then insert into the map sequentially in that same order.
-        struct TriJob { int tid; TrackHist* th; const ObsList* hist; const Pose* p0; const Pose* pl; V3 X; bool ok; };
-        std::vector<TriJob> jobs;
+      clk.bookkeeping += since(tb0);
+      // triangulation jobs (T:1801-1813).  The DLT solves (libm Jacobi) are independent: gather the jobs in the reference's
+      // iteration order, solve them on the host pool, then insert into the map sequentially in that same order.
+      struct TriJob { int tid; TrackHist* th; const ObsList* hist; const Pose* p0; const Pose* pl; V3 X; bool ok; };
+      std::vector<TriJob> jobs;
+      const auto th0 = Clock::now();
+      if (kfs.size() >= 1) {
         for (auto& kv : track_hist) {
           const int tid = kv.first;
           auto& hist = kv.second.obs;
@@ -1712,7 +1720,24 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           const Pose* pl = (idl < (int)kfs.size()) ? &kfs[(size_t)idl].pose : &kf.pose;
           jobs.push_back(TriJob{tid, &kv.second, &hist, &kfs[(size_t)id0].pose, pl, V3{}, true});
         }
-        clk.tri_iter += since(th0);
+      }
+      clk.tri_iter += since(th0);
+      clk.host += since(th0);
+      if (late_join) {
+        looped = join_c();
+        if (looped) { join_b(); finish_loop(); }
+        for (const auto& ob : late_obs) map.add_obs(ob.first, kf.kf_id, ob.second);
+      }
+      if (edge_prev_id >= 0 && ei.size() >= 80) {
+        pending_edges.push_back(PendingEdge{edge_prev_id, kf.kf_id, nullptr});
+        PendingEdge* slot = &pending_edges.back();  // std::deque: stays valid while later edges are appended
+        auto task = [slot, ectx, eclk, K, ransac_ahead, ei = std::move(ei), ej = std::move(ej)]() {
+          slot->ra = ransac_ahead(ectx, K, ei, ej, 2500, 1e-3, 60, eclk);
+        };
+        if (edge_lane) edge_lane->submit(std::move(task));
+        else task();
+      }
+      if (kfs.size() >= 1) {
         // the walk above only reads the track histories; the solves below read the keyframe poses BA(k-1) refines
         if (!looped) join_b();
         const auto ts0 = Clock::now();
@@ -1729,7 +1754,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
           for (const auto& ob : *j.hist) map.add_obs(j.tid, ob.first, ob.second);
         }
         clk.tri_insert += since(ti0);
-        clk.host += since(th0);
+        clk.host += since(ts0);
       } else if (!looped) {
         join_b();
       }

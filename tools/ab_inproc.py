@@ -36,6 +36,7 @@ for _ in range(3):
     one()
 ms = {n: [] for n, _ in variants}
 klt = {n: [] for n, _ in variants}
+extra = {n: {k: [] for k in ("sec_lane_b_busy", "sec_join_wait", "sec_m_kf", "sec_feed_wait", "sec_m_step")} for n, _ in variants}
 ref_log = None
 for rep in range(args.reps):
     for name, env in variants:
@@ -46,10 +47,13 @@ for rep in range(args.reps):
             dt, r = one()
             ms[name].append(dt * 1e3)
             klt[name].append(r["stats"]["sec_klt"] * 1e3)
+            for k in extra[name]:
+                extra[name][k].append(r["stats"][k] * 1e3)
             if ref_log is None:
                 ref_log = r["log"]
             assert r["log"] == ref_log, f"variant {name} changed the output"
 for name, _ in variants:
     a = np.array(ms[name])
     print(f"{name:14s} passes {len(a):3d}: median {np.median(a):6.2f} ms  mean {a.mean():6.2f}  p10 {np.percentile(a, 10):6.2f}  p90 {np.percentile(a, 90):6.2f}"
-          f"  -> {47e3 / np.median(a):7.1f} keyframes/s (median) | tracker-lane KLT wall {np.median(klt[name]):5.2f} ms", flush=True)
+          f"  -> {47e3 / np.median(a):7.1f} keyframes/s (median) | tracker-lane KLT wall {np.median(klt[name]):5.2f} ms | "
+          + " ".join(f"{k[4:]} {np.median(v):5.2f}" for k, v in extra[name].items()), flush=True)

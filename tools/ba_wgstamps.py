@@ -20,7 +20,7 @@ TMP = "/tmp/wgstamps.bin"
 
 def dump():
     n = lib.sfmx_debug_dump_wgstamps(TMP.encode())
-    a = np.fromfile(TMP, dtype=np.uint64).reshape(-1, 4) if n > 0 else np.zeros((0, 4), np.uint64)
+    a = np.fromfile(TMP, dtype=np.uint64).reshape(-1, 8) if n > 0 else np.zeros((0, 8), np.uint64)
     return a
 
 
@@ -59,6 +59,16 @@ def report(tag, a):
         q = lambda v: f"{np.median(v):6.1f} (p10 {np.percentile(v,10):5.1f}, p90 {np.percentile(v,90):6.1f})"
         print(f"{tag} {name}: {len(ls)} launches x {len(ls[0])} workgroups | span us {q(span)} | start skew us {q(skew)} | workgroup us median {q(dur_med)} "
               f"| slowest workgroup us {q(dur_max)} | CUs used {np.median(ncu):.0f}, most workgroups on one CU {np.median(percu):.0f}", flush=True)
+        # phase marks (us after the workgroup's own start; median over workgroups and launches; 0 = mark not reached)
+        allr = np.concatenate(ls)
+        marks = []
+        for i in range(4):
+            m = allr[:, 4 + i].astype(np.int64) - allr[:, 0].astype(np.int64)
+            m = m[allr[:, 4 + i] != 0]
+            marks.append(f"m{i} {np.median(m) / 100.0:5.1f}" if len(m) else f"m{i}   -  ")
+        end = (allr[:, 1].astype(np.int64) - allr[:, 0].astype(np.int64)) / 100.0
+        names = "inputs | observations | sums+inverse+gain | rows issued" if kind == 1 else "first loads issued | chains done | ticket taken | -"
+        print(f"{tag} {name}: marks ({names}): " + "  ".join(marks) + f"  end {np.median(end):5.1f}", flush=True)
 
 
 # ---- alone
