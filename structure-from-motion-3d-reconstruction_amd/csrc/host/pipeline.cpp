@@ -1014,6 +1014,26 @@ void AsyncLane::submit(std::function<void()> task) {
   }
   cv_task_.notify_one();
 }
+std::uint64_t AsyncLane::submit_ticket(std::function<void()> task) {
+  std::uint64_t t;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    queue_.push_back(std::move(task));
+    t = submitted_.fetch_add(1, std::memory_order_release) + 1;
+  }
+  cv_task_.notify_one();
+  return t;
+}
+void AsyncLane::wait_ticket(std::uint64_t ticket) {
+  (void)spin_until([&] { return completed_.load(std::memory_order_acquire) >= ticket; }, spin_us_.load(std::memory_order_relaxed));
+  std::unique_lock<std::mutex> lk(mu_);
+  cv_idle_.wait(lk, [&] { return completed_.load(std::memory_order_acquire) >= ticket; });
+  if (error_) {
+    std::exception_ptr e = error_;
+    error_ = nullptr;
+    std::rethrow_exception(e);
+  }
+}
 void AsyncLane::wait() {
   const std::uint64_t want = submitted_.load(std::memory_order_acquire);
   (void)spin_until([&] { return completed_.load(std::memory_order_acquire) >= want; }, spin_us_.load(std::memory_order_relaxed));
@@ -1394,10 +1414,11 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   std::unique_ptr<AsyncLane> lane_a, lane_a2;  // lane_a2 (SFMX_RANSAC_LANES=2): odd frames, so that a call has two frame times
   if (track_lane && !std::getenv("SFMX_NO_RANSAC_LANE")) {
     lane_a = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A);
-    // a second lane for the odd frames when a call is expensive (its cost grows with the number of correspondences): with 5 000
-    // tracks per frame (C3) lane A was busy 1.23 s of a 2.2 s pass and the geometry thread waited for it -- 437 -> 543 frames/s with
-    // two lanes; at the reference's 2 200 tracks the second lane changes nothing (SFMX_RANSAC_LANES=1|2 overrides)
-    int ransac_lanes = cfg.klt.max_tracks > 3000 ? 2 : 1;
+    // a second lane for the odd frames: a call (kernels + exact host hypotheses + decomposition) takes ~490 us of lane time at the
+    // reference's 2 200 tracks, more than the geometry thread needs per frame since it stopped waiting for the loop verdict first
+    // (29.9 -> 29.0 ms per 47-frame pass, profiles/r03_ab_inproc_rl.txt); with 5 000 tracks per frame (C3) lane A was busy 1.23 s
+    // of a 2.2 s pass: 437 -> 543 frames/s with two lanes (SFMX_RANSAC_LANES=1|2 overrides)
+    int ransac_lanes = 2;
     if (const char* e = std::getenv("SFMX_RANSAC_LANES")) ransac_lanes = std::atoi(e);
     if (ransac_lanes >= 2) lane_a2 = std::make_unique<AsyncLane>(sfmx_ctx_device(ctx), prio_env("SFMX_PRIO_LANE_A", 0), ContextPool::LANE_A2);
   }
@@ -1493,6 +1514,9 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   sfmx_ctx* cctx = lane_c ? lane_c->ctx() : ctx;
   StageClock* cclk = lane_c ? &lane_c_clk : &clk;
   AsyncLane* edge_lane = lane_e ? lane_e.get() : lane_c.get();  // where the keyframe->keyframe RANSAC runs
+  // the loop verification of a keyframe goes to lane C at the top of the keyframe's block (it needs a lane C of its own: the join
+  // then waits for that one task, not for the lane); SFMX_VERIFY_LATE=1: where the reference has it, after the BA submit (A/B, tests)
+  const bool verify_early = lane_c && lane_e && !std::getenv("SFMX_VERIFY_LATE");
   sfmx_ctx* ectx = lane_e ? lane_e->ctx() : cctx;
   StageClock* eclk = lane_e ? &lane_e_clk : cclk;
   GpuBundleAdjuster ba(bctx, bclk, cfg.comm_ba, lane ? &lane->pooled()->ba : nullptr);
@@ -1501,7 +1525,16 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   struct PendingEdge { int i, j; std::shared_ptr<RansacAhead> ra; };
   std::deque<PendingEdge> pending_edges;
   BaJob pending_ba;
-  struct PendingLoop { bool active = false; int frame = -1, old_kf = -1, new_kf = -1; std::shared_ptr<RansacAhead> ra; std::optional<RelPose> rel; } pending_loop;
+  // loop-closure verification of a keyframe (lane C): `cell` receives its RANSAC result, `ticket` is the lane task to wait for.
+  // queued_loop: submitted at the START of a keyframe block (SFMX_VERIFY_LATE unset), promoted to pending_loop where the
+  // reference runs the detection (after the keyframe's BA, T:1822) -- the verdict is consumed at the next keyframe either way
+  struct PendingLoop {
+    bool active = false;
+    int frame = -1, old_kf = -1, new_kf = -1;
+    std::shared_ptr<std::shared_ptr<RansacAhead>> cell;
+    std::optional<RelPose> rel;
+    std::uint64_t ticket = 0;
+  } pending_loop, queued_loop;
   struct LaneGuard {  // declared after everything the lanes' tasks reference: drained first when unwinding
     AsyncLane *l, *m, *e;
     ~LaneGuard() {
@@ -1536,20 +1569,26 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
   };
   auto join_c = [&]() -> bool {
     const auto tj = Clock::now();
-    if (lane_c) lane_c->wait();
+    if (lane_c) {
+      // with the verification of the NEXT keyframe possibly queued behind it, only the pending one is waited for
+      if (pending_loop.active && pending_loop.ticket) lane_c->wait_ticket(pending_loop.ticket);
+      else if (!queued_loop.active) lane_c->wait();
+    }
     clk.join_wait += since(tj);
     if (pending_loop.active) {  // verdict of the loop-closure verification of the last keyframe (T:1858)
       PendingLoop pl = pending_loop;
       pending_loop = PendingLoop{};
-      if (pl.ra) pl.rel = ransac_finish(*pl.ra);
+      if (pl.cell && *pl.cell) pl.rel = ransac_finish(**pl.cell);
       if (pl.rel && (int)pl.rel->inliers.size() >= 100) accepted_loop = pl;
     }
     return accepted_loop.has_value();
   };
+  double t_join_b = 0;  // (SFMX_TRACE_PHASES: lane B's share of join_wait)
   auto join_b = [&]() {
     const auto tj = Clock::now();
     if (lane) lane->wait();
     clk.join_wait += since(tj);
+    t_join_b += since(tj);
     GpuBundleAdjuster::apply(pending_ba, kfs);
     pending_ba = BaJob{};
   };
@@ -1662,6 +1701,67 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       // from them) and the list of pending edges (the loop edge goes in front of this keyframe's sequential edge) -- is touched
       // only after the join.  SFMX_JOIN_C_EARLY=1: the join first, as before (A/B and tests; identical output).
       const bool late_join = std::getenv("SFMX_JOIN_C_EARLY") == nullptr;
+      // Loop-closure detection and verification of THIS keyframe (T:1822-1866).  Neither reads anything the rest of the block
+      // produces -- the candidate comes from the global descriptors, the correspondences from the two images and the old
+      // keyframe's corner sequence -- so the verification is handed to lane C before everything else (with its own lane for the
+      // edges: verify_early) and has the whole keyframe block to finish in; its verdict is consumed at the next keyframe as before.
+      // new_id / n_after: this keyframe's id and the keyframe count once it has been pushed.
+      auto detect_loop = [&](int new_id, int n_after, PendingLoop& dst) {
+        const std::vector<float>& desc_new = pkt.desc;
+        int best_id = -1;
+        float best_score = 0.0f;
+        for (int kk = 0; kk < n_after - 6; ++kk) {
+          const float s = dot_desc(kf_desc[(size_t)kk], desc_new);
+          if (s > best_score) { best_score = s; best_id = kk; }
+        }
+        if (!(best_id >= 0 && best_score > 0.94f)) return;
+        const Keyframe& old_kf = kfs[(size_t)best_id];
+        LKConfig lc = cfg.klt;
+        lc.max_tracks = loop_corners;
+        lc.min_tracks = 600;
+        // corners of the old keyframe image (T:1841): a prefix of the sequence found when that frame was current (same
+        // image, quality, min_dist); detected here only if the tracker never replenished on that frame
+        std::vector<V2> pts0;
+        {
+          const auto ts0 = Clock::now();
+          clk.shi_calls++;
+          auto itc = kf_corners.find(old_kf.frame_idx);
+          if (itc != kf_corners.end() && itc->second->serves(lc.max_tracks, lc.quality, lc.min_distance)) {
+            clk.shi_memo_hits++;
+            pts0 = itc->second->prefix(lc.max_tracks);
+          } else {
+            if (!old_pyr) check(ctx, sfmx_pyramid_create(ctx, w, h, feeder.levels_total(), &old_pyr), "pyramid_create");
+            src.load(ctx, old_kf.frame_idx, old_pyr);
+            pts0 = geo_det.detect(old_pyr, lc.max_tracks, lc.quality, lc.min_distance);
+            kf_corners[old_kf.frame_idx] = std::make_shared<const CornerMemo>(
+                CornerMemo{lc.quality, lc.min_distance, lc.max_tracks, (int)pts0.size() < lc.max_tracks, pts0});
+          }
+          clk.shi += since(ts0);
+        }
+        auto cell = std::make_shared<std::shared_ptr<RansacAhead>>();
+        dst = PendingLoop{true, fi, old_kf.kf_id, new_id, cell, std::nullopt, 0};
+        const int old_frame = old_kf.frame_idx;
+        const sfmx_pyramid* cur_pyr = pkt.pyr;  // not released to the tracker lane while this verification is pending
+        auto verify = [&, cell, lc, old_frame, cur_pyr, pts0 = std::move(pts0)]() {
+          sfmx_pyramid* opc = old_pyr_c;
+          if (lane_c) opc = lane_c->pooled()->pyramid(w, h, feeder.levels_total());  // lives with the pooled context
+          else if (!opc) { check(cctx, sfmx_pyramid_create(cctx, w, h, feeder.levels_total(), &old_pyr_c), "pyramid_create"); opc = old_pyr_c; }
+          src.load(cctx, old_frame, opc);
+          std::vector<V2> fwd;
+          std::vector<std::uint8_t> keep;
+          klt_pairs(cctx, lc, opc, cur_pyr, pts0, fwd, keep, cclk);
+          std::vector<V2> li, lj;
+          for (size_t i = 0; i < pts0.size(); i++) {
+            if (!keep[i]) continue;
+            li.push_back(pts0[i]);
+            lj.push_back(fwd[i]);
+          }
+          if (li.size() >= 120) *cell = ransac_ahead(cctx, K, li, lj, 4000, 2e-3, 80, cclk);
+        };
+        if (lane_c) dst.ticket = lane_c->submit_ticket(std::move(verify));
+        else { verify(); join_lane(); }
+      };
+      if (verify_early) detect_loop((int)kfs.size(), (int)kfs.size() + 1, queued_loop);
       bool looped = false;
       if (!late_join) {
         looped = join_c();
@@ -1770,59 +1870,12 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       else ba.solve(pending_ba);
       if (!lane) join_lane();
 
-      // loop closure (T:1822-1866)
-      const int new_kf_id = kfs.back().kf_id;
-      int best_id = -1;
-      float best_score = 0.0f;
-      for (int kk = 0; kk < (int)kfs.size() - 6; ++kk) {
-        const float s = dot_desc(kf_desc[(size_t)kk], new_desc);
-        if (s > best_score) { best_score = s; best_id = kk; }
-      }
-      if (best_id >= 0 && best_score > 0.94f) {
-        const Keyframe& old_kf = kfs[(size_t)best_id];
-        LKConfig lc = cfg.klt;
-        lc.max_tracks = loop_corners;
-        lc.min_tracks = 600;
-        // corners of the old keyframe image (T:1841): a prefix of the sequence found when that frame was current (same
-        // image, quality, min_dist); detected here only if the tracker never replenished on that frame
-        std::vector<V2> pts0;
-        {
-          const auto ts0 = Clock::now();
-          clk.shi_calls++;
-          auto itc = kf_corners.find(old_kf.frame_idx);
-          if (itc != kf_corners.end() && itc->second->serves(lc.max_tracks, lc.quality, lc.min_distance)) {
-            clk.shi_memo_hits++;
-            pts0 = itc->second->prefix(lc.max_tracks);
-          } else {
-            if (!old_pyr) check(ctx, sfmx_pyramid_create(ctx, w, h, feeder.levels_total(), &old_pyr), "pyramid_create");
-            src.load(ctx, old_kf.frame_idx, old_pyr);
-            pts0 = geo_det.detect(old_pyr, lc.max_tracks, lc.quality, lc.min_distance);
-            kf_corners[old_kf.frame_idx] = std::make_shared<const CornerMemo>(
-                CornerMemo{lc.quality, lc.min_distance, lc.max_tracks, (int)pts0.size() < lc.max_tracks, pts0});
-          }
-          clk.shi += since(ts0);
-        }
-        pending_loop = PendingLoop{true, fi, old_kf.kf_id, new_kf_id, nullptr, std::nullopt};
-        const int old_frame = old_kf.frame_idx;
-        const sfmx_pyramid* cur_pyr = pkt.pyr;  // not released to the tracker lane while this verification is pending
-        auto verify = [&, lc, old_frame, cur_pyr, pts0 = std::move(pts0)]() {
-          sfmx_pyramid* opc = old_pyr_c;
-          if (lane_c) opc = lane_c->pooled()->pyramid(w, h, feeder.levels_total());  // lives with the pooled context
-          else if (!opc) { check(cctx, sfmx_pyramid_create(cctx, w, h, feeder.levels_total(), &old_pyr_c), "pyramid_create"); opc = old_pyr_c; }
-          src.load(cctx, old_frame, opc);
-          std::vector<V2> fwd;
-          std::vector<std::uint8_t> keep;
-          klt_pairs(cctx, lc, opc, cur_pyr, pts0, fwd, keep, cclk);
-          std::vector<V2> li, lj;
-          for (size_t i = 0; i < pts0.size(); i++) {
-            if (!keep[i]) continue;
-            li.push_back(pts0[i]);
-            lj.push_back(fwd[i]);
-          }
-          if (li.size() >= 120) pending_loop.ra = ransac_ahead(cctx, K, li, lj, 4000, 2e-3, 80, cclk);
-        };
-        if (lane_c) lane_c->submit(std::move(verify));
-        else { verify(); join_lane(); }
+      // loop closure (T:1822-1866): detection + verification were started at the top of this block (detect_loop), or start here
+      if (verify_early) {
+        pending_loop = queued_loop;
+        queued_loop = PendingLoop{};
+      } else {
+        detect_loop(kfs.back().kf_id, (int)kfs.size(), pending_loop);
       }
     }
     clk.m_kf += since(tm2);
@@ -1833,7 +1886,7 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
     release_frames(fi);
     t_rel += since(tr0);
   }
-  if (trace_phases) std::fprintf(stderr, "loop parts: parallax %.3f emit %.3f release %.3f first-frame %.3f loop-join %.3f feed %.3f ransac %.3f kf %.3f ms\n", t_par * 1e3, t_emit * 1e3, t_rel * 1e3, t_first * 1e3, t_loopjoin * 1e3, clk.feed_wait * 1e3, clk.m_ransac * 1e3, clk.m_kf * 1e3);
+  if (trace_phases) std::fprintf(stderr, "loop parts: parallax %.3f emit %.3f release %.3f first-frame %.3f loop-join %.3f feed %.3f ransac %.3f kf %.3f (join B %.3f, join C %.3f) ms\n", t_par * 1e3, t_emit * 1e3, t_rel * 1e3, t_first * 1e3, t_loopjoin * 1e3, clk.feed_wait * 1e3, clk.m_ransac * 1e3, clk.m_kf * 1e3, t_join_b * 1e3, (clk.join_wait - t_join_b) * 1e3);
   phase("frame loop done");
   join_lane();
   flush_edges();

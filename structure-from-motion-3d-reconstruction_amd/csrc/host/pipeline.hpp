@@ -450,6 +450,10 @@ class AsyncLane {
   sfmx_ctx* ctx() const { return ctx_; }
   PooledCtx* pooled() const { return pc_; }
   void submit(std::function<void()> task);
+  // the same, returning the task's ticket: wait_ticket(t) returns once that task (and every task before it) has finished --
+  // tasks submitted after it may still be running
+  std::uint64_t submit_ticket(std::function<void()> task);
+  void wait_ticket(std::uint64_t ticket);
   void wait();
   double busy_seconds() const { return busy_seconds_; }  // time spent inside tasks (read while idle)
   // this lane's own polling window before it (and whoever waits for it) sleeps; -1 = the process-wide SFMX_SPIN_US
