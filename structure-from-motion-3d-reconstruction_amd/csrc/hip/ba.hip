@@ -457,10 +457,10 @@ __global__ __launch_bounds__(64) void k_ba_points_bulk(BA_POINTS_PARAMS) { ba_po
 // Precondition (checked on the host when the problem is set up): no pose observes a point twice (that case is a read-modify-write
 // of the slot record, which stays with the general kernel); points with more than BA_MAX_OBS observations contribute nothing
 // (T:915-918).  WT: window size as a compile-time constant (0 = read W), so that the row-entry decoding divides by constants.
-template <int WT>
+template <int WT, int PTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_ba_points_window_lds(BA_POINTS_PARAMS) {
   WGS_BEGIN;
-  constexpr int PTS = BA_PTS;
+  static_assert(PTS * BA_MAX_OBS <= 64, "one wave runs the per-observation phases");
   extern __shared__ __align__(16) double s_rec[];  // [PTS][MS][BA_SLOT]
   __shared__ double sp[BA_MAX_W * 12];
   __shared__ double s_term[PTS][BA_MAX_OBS][12];
@@ -475,16 +475,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   // ---- inputs: poses, the observation lists of the points (one lane per observation), empty slot tables
   for (int i = tid; i < Wc * 12; i += 256) sp[i] = poses[i];
   for (int i = tid; i < PTS * Wc; i += 256) s_so[i / Wc][i % Wc] = -1;
+  double ob_u = 0.0, ob_v = 0.0, pt_x = 0.0, pt_y = 0.0, pt_z = 0.0;  // this lane's observation and its point, fetched with the lists
   if (tid < PTS * BA_MAX_OBS) {
     const int p = p0 + pt;
     int o0 = 0, cnt = 0;
     if (p < P) {
       o0 = obs_ptr[p];
       cnt = obs_ptr[p + 1] - o0;
+      pt_x = X[3 * p]; pt_y = X[3 * p + 1]; pt_z = X[3 * p + 2];
     }
     if (cnt > BA_MAX_OBS) cnt = 0;  // T:915-918: the point is skipped as a whole
     if (k == 0) { s_o0[pt] = o0; s_n[pt] = cnt; }
-    s_li[pt][k] = k < cnt ? obs_li[o0 + k] : -1;
+    int li = -1;
+    if (k < cnt) {
+      li = obs_li[o0 + k];
+      ob_u = obs_uv[2 * (o0 + k)];
+      ob_v = obs_uv[2 * (o0 + k) + 1];
+    }
+    s_li[pt][k] = li;
   }
   __syncthreads();
   WGS_MARK(0);  // inputs staged
@@ -506,13 +514,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   __syncthreads();
   // ---- one lane per observation: the slot record (Hxx | bx | Hxp) and the twelve terms of Hpp | bp
   if (tid < PTS * BA_MAX_OBS && k < s_n[pt]) {
-    const int p = p0 + pt, sl = s_slot[pt][k];
+    const int sl = s_slot[pt][k];
     bool adds = false;
-    if (sl >= 0) {
-      const int o = s_o0[pt] + k;
-      adds = ba_observation<true>(s_rec + ((size_t)pt * MS + sl) * BA_SLOT, sp + 12 * s_li[pt][k], X[3 * p], X[3 * p + 1], X[3 * p + 2], obs_uv[2 * o],
-                                  obs_uv[2 * o + 1], fx, fy, cx, cy, huber, s_term[pt][k]);
-    }
+    if (sl >= 0)
+      adds = ba_observation<true>(s_rec + ((size_t)pt * MS + sl) * BA_SLOT, sp + 12 * s_li[pt][k], pt_x, pt_y, pt_z, ob_u, ob_v, fx, fy, cx, cy, huber,
+                                  s_term[pt][k]);
     s_adds[pt][k] = adds ? 1 : 0;
   }
   __syncthreads();
@@ -971,7 +977,7 @@ __global__ __launch_bounds__(64) void k_solve_regs_stamps(const double* __restri
 // the barrier that follows the chain over tile t).  Window-sized problems run <64, N, 2, 2>: 32 KiB of LDS and 96 VGPRs -- a
 // small footprint finds a CU sooner next to KLT workgroups.  The streaming shape that C4 uses is <128, N, 2, 2>: 64 KiB of
 // LDS, half as many barriers per point (C4 reduction 1.14 -> 0.91 ms; <64, N, 4, 3> before).
-template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
+template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF, bool LOOKAHEAD = false>
 __device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __restrict__ C, double lambda, int damp, double* __restrict__ S,
                                                double* __restrict__ b, unsigned* __restrict__ ticket, double* __restrict__ work,
                                                double* __restrict__ host_out, unsigned long long seq, int wave_prio, const double* init,
@@ -1039,7 +1045,9 @@ __device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __res
         if (tid < BAR_COLS) {
           // the LDS reads of the next batch of rows are issued before the dependent adds of the current one
           const int cnt = min(BAR_TP, P - t * BAR_TP);
-          if (cnt == BAR_TP && BAR_NPF <= 2 && BAR_TP <= 64) {  // window shape: one batch in registers (32 VGPRs less than the look-ahead below)
+          // (LOOKAHEAD for the window shape was measured with workgroup timestamps: chains done at 12.9 us against 13.1 -- the adds
+          // themselves are the time; not instantiated)
+          if (cnt == BAR_TP && BAR_NPF <= 2 && BAR_TP <= 64 && !LOOKAHEAD) {  // one batch in registers (32 VGPRs less than the look-ahead below)
             if (any_two) {
 #pragma unroll
               for (int bch = 0; bch < BAR_TP / 8; bch++) {
@@ -1169,7 +1177,7 @@ __device__ __forceinline__ void ba_reduce_body(int W, int P, const double* __res
   }
 }
 
-template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF>
+template <int BAR_TP, int SOLVE_N, int BAR_NPF, int BAR_NBUF, bool LOOKAHEAD = false>
 __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* __restrict__ C, double lambda, int damp,
                                                    double* __restrict__ S, double* __restrict__ b,
                                                    unsigned* __restrict__ ticket, double* __restrict__ work, double* __restrict__ host_out,
@@ -1177,8 +1185,8 @@ __global__ __launch_bounds__(256) void k_ba_reduce(int W, int P, const double* _
                                                    int publish_system = 0) {
   // wg_off: element-sharded launches cover a slice of the element blocks
   WGS_BEGIN;
-  ba_reduce_body<BAR_TP, SOLVE_N, BAR_NPF, BAR_NBUF>(W, P, C, lambda, damp, S, b, ticket, work, host_out, seq, wave_prio, init,
-                                                     (int)blockIdx.x + wg_off, (int)gridDim.x, publish_system WGS_ARG);
+  ba_reduce_body<BAR_TP, SOLVE_N, BAR_NPF, BAR_NBUF, LOOKAHEAD>(W, P, C, lambda, damp, S, b, ticket, work, host_out, seq, wave_prio, init,
+                                                                (int)blockIdx.x + wg_off, (int)gridDim.x, publish_system WGS_ARG);
 #ifdef SFMX_BA_WGSTAMPS
   // (the body returns early in all workgroups but the last of a fused launch: stamped here only when it falls through)
 #endif
@@ -1653,16 +1661,25 @@ static int ba_launch_points(sfmx_ctx* c, sfmx_ba_problem* q, const double* d_pos
                             int wave_prio) {
   // SFMX_BA_POINTS=global: the window kernel with its records in global memory (A/B and tests; identical rows)
   const char* pts_env = getenv("SFMX_BA_POINTS");
-  const size_t rec_lds = (size_t)BA_PTS * q->MS * BA_SLOT * 8 + 16;
+  // points per workgroup of the LDS kernel (SFMX_BA_PTS=1|2|4): the record phases keep 16 lanes per point busy whatever the count,
+  // the row expansion is the workgroup's throughput-bound part and scales with it
+  int pts_wg = 2;
+  if (const char* e = getenv("SFMX_BA_PTS")) pts_wg = atoi(e);
+  if (pts_wg != 1 && pts_wg != 4) pts_wg = 2;
+  const size_t rec_lds = (size_t)pts_wg * q->MS * BA_SLOT * 8 + 16;
   if (ba_merged(q) && q->lds_points && rec_lds <= 40960 && !(pts_env && pts_env[0] == 'g')) {
-    const int nwg = (q->P + BA_PTS - 1) / BA_PTS;
-    if (q->W == 6) {
-      SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window_lds<6><<<nwg, 256, rec_lds, c->stream>>>(
-                                      q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
-    } else {
-      SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window_lds<0><<<nwg, 256, rec_lds, c->stream>>>(
-                                      q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));
-    }
+    const int nwg = (q->P + pts_wg - 1) / pts_wg;
+#define BA_PL_ARGS q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio
+#define BA_PL_LAUNCH(WT_)                                                                                                     \
+  do {                                                                                                                        \
+    if (pts_wg == 1) SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window_lds<WT_, 1><<<nwg, 256, rec_lds, c->stream>>>(BA_PL_ARGS)));      \
+    else if (pts_wg == 2) SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window_lds<WT_, 2><<<nwg, 256, rec_lds, c->stream>>>(BA_PL_ARGS))); \
+    else SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window_lds<WT_, 4><<<nwg, 256, rec_lds, c->stream>>>(BA_PL_ARGS)));                  \
+  } while (0)
+    if (q->W == 6) BA_PL_LAUNCH(6);
+    else BA_PL_LAUNCH(0);
+#undef BA_PL_LAUNCH
+#undef BA_PL_ARGS
   } else if (ba_merged(q)) {
     SFMX_PROF(c, KID_BA_POINTS, (k_ba_points_window<<<(q->P + BA_PTS - 1) / BA_PTS, 256, 0, c->stream>>>(
                                     q->W, q->P, q->MS, d_poses, q->X, q->obs_ptr, q->obs_li, q->obs_uv, fx, fy, cx, cy, huber, q->rec, q->slot_of, q->contrib, wave_prio)));

@@ -81,6 +81,8 @@ for _ in range(40):
     prob.step(pw, K[0, 0], K[1, 1], K[0, 2], K[1, 2], 3.0, 1e-3)
 report("alone   ", dump())
 prob.close()
+if os.environ.get("STAMPS_ALONE_ONLY"):
+    sys.exit(0)
 # ---- inside the pipeline
 seq = I.synth.make_sequence(47, 640, 480, 0.3, n_blobs=20000, seed=7)
 cfg = dict(pipe.DEFAULTS, frames=47, max_tracks=2200, min_tracks=900, export_pointcloud=0)
