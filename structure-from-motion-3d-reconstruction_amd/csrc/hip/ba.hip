@@ -8,6 +8,7 @@
 //      per-(point,pose) Hxx/bx/Hxp exactly as T:920-1009, then inv3(Hpp) and G = Hxp * Hpp^-1, G*bp (T:1011-1041).
 //      Output is one compact RECORD per point (84 doubles per observing pose) plus a pose->slot table; poses (W x 12
 //      doubles) sit in LDS.  Window shape: sixteen lanes per point (one per observation), followed in the same launch by
+//      (k_ba_points_window_lds: the same with observation lists, slot tables and slot records in LDS -- the window default)
 //  the expansion (k_ba_expand for large problems): every addend the reference will add into S,b for a point -- the
 //      Schur term G_a * Hxp_b^T per element, Hxx, bx, G*bp -- written as one contiguous contribution row per point.
 //  k_ba_reduce  (16 elements of S | b per workgroup): ordered column sums over the contribution rows in the reference's
