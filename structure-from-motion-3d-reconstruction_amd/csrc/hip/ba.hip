@@ -463,12 +463,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   WGS_BEGIN;
   static_assert(PTS * BA_MAX_OBS <= 64, "one wave runs the per-observation phases");
   extern __shared__ __align__(16) double s_rec[];  // [PTS][MS][BA_SLOT]
-  __shared__ double sp[BA_MAX_W * 12];
+  constexpr int WCAP = WT ? WT : BA_MAX_W;         // (a known window size keeps the static LDS at what it needs: 5.5 KB less at W = 6)
+  __shared__ double sp[WCAP * 12];
   __shared__ double s_term[PTS][BA_MAX_OBS][12];
   __shared__ double s_H[PTS][12], s_iH[PTS][9];
   __shared__ int s_n[PTS], s_na[PTS], s_ok[PTS], s_o0[PTS];
   __shared__ int s_li[PTS][BA_MAX_OBS];
-  __shared__ int8_t s_slot[PTS][BA_MAX_OBS], s_adds[PTS][BA_MAX_OBS], s_so[PTS][BA_MAX_W];
+  __shared__ int8_t s_slot[PTS][BA_MAX_OBS], s_adds[PTS][BA_MAX_OBS], s_so[PTS][WCAP];
   if (wave_prio) __builtin_amdgcn_s_setprio(3);
   const int Wc = WT ? WT : W;
   const int tid = threadIdx.x, p0 = (int)blockIdx.x * PTS;
@@ -1695,11 +1696,17 @@ static int ba_element_blocks(const sfmx_ba_problem* q) { const int D = 6 * q->W;
 static void ba_reduce_kernel(sfmx_ctx* c, sfmx_ba_problem* q, const double* rows, int p_cnt, double lambda, int damp, double* S_out, double* b_out,
                              const double* init, bool fused_solve, double* host_out, unsigned long long seq, int wave_prio, int wg_lo, int nwg,
                              int publish_system, bool streaming) {
-  // SFMX_BA_TILE=32: 32-row tiles with a four-tile register ring for the window shape -- 16 KB of LDS per workgroup instead of 33
-  // (a workgroup then fits next to six resident KLT waves of a CU instead of five); A/B switch, identical sums
+  // Rows per tile of the window shape (SFMX_BA_TILE=64|32|16; the register ring always holds 128 rows of look-ahead): 33 / 16 / 11 KB
+  // of LDS per workgroup.  A workgroup of the reduction starts when a CU has that much LDS free next to the resident KLT waves
+  // (22.6 KB each, up to seven per CU): with the BA chain bounding a pass again, 32-row tiles are 1.5 % faster than 64-row ones
+  // (profiles/r03_ab_inproc_lds.txt); identical sums.
   const char* tile_env = getenv("SFMX_BA_TILE");
-  if (fused_solve && q->W == 6 && tile_env && atoi(tile_env) == 32) {
+  const int tile_rows = tile_env ? atoi(tile_env) : 32;
+  if (fused_solve && q->W == 6 && tile_rows == 32) {
     k_ba_reduce<32, 36, 4, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, q->ticket, q->work, host_out, seq, wave_prio, init,
+                                                         wg_lo, publish_system);
+  } else if (fused_solve && q->W == 6 && tile_rows == 16) {
+    k_ba_reduce<16, 36, 8, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, q->ticket, q->work, host_out, seq, wave_prio, init,
                                                          wg_lo, publish_system);
   } else if (fused_solve && q->W == 6) {
     k_ba_reduce<64, 36, 2, 2><<<nwg, 256, 0, c->stream>>>(q->W, p_cnt, rows, lambda, damp, S_out, b_out, q->ticket, q->work, host_out, seq, wave_prio, init,
@@ -2075,6 +2082,15 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
   const bool poll = !c->timing && !no_poll;  // the event timers need the stream synchronisation
   const bool fuse = ba_can_fuse_solve(q) && !no_fuse;
   const bool host_solve = host_solve_on && poll && fuse;
+  // SFMX_BA_HOST_TIMES=1 (diagnostic): where a step's wall time goes on the host -- launches, wait for the published system, solve,
+  // and the time between two steps (the caller's pose update) -- averaged over 1 000 steps, on stderr
+  static const bool host_times = getenv("SFMX_BA_HOST_TIMES") != nullptr;
+  static double ht_launch = 0, ht_wait = 0, ht_solve = 0, ht_between = 0;  // (one BA lane at a time; a diagnostic)
+  static unsigned ht_n = 0;
+  static std::chrono::steady_clock::time_point ht_last_exit;
+  const auto ht0 = std::chrono::steady_clock::now();
+  auto ht_us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  if (host_times && ht_n > 0 && ht_us(ht_last_exit, ht0) < 200.0) ht_between += ht_us(ht_last_exit, ht0);
   KernelTimer t(c);
   SFMX_HIP(c, c->h[1].ensure(host_solve ? (size_t)NE * 8 + 32 : (size_t)D * 8 + 32));
   double* hout = c->h[1].as<double>();
@@ -2099,6 +2115,7 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
       SFMX_HIP(c, hipGetLastError());
     }
     const auto t0 = std::chrono::steady_clock::now();
+    if (host_times) ht_launch += ht_us(ht0, t0);
     unsigned spins = 0;
     while (__atomic_load_n(const_cast<unsigned long long*>(flag), __ATOMIC_ACQUIRE) != seq) {
       __builtin_ia32_pause();
@@ -2112,7 +2129,20 @@ int sfmx_ba_step(sfmx_ctx* c, sfmx_ba_problem* q, const double* poses_wc, double
     if (host_solve) {
       double work[60 * 61];
       static_assert(BA_MAX_W >= 10, "window sizes with a fused reduction: 6 and 10 poses");
+      const auto ts = std::chrono::steady_clock::now();
       status = sfmx_host_solve_window(hout, hout + (size_t)D * D, D, dx_out, work);
+      if (host_times) {
+        const auto te = std::chrono::steady_clock::now();
+        ht_wait += ht_us(t0, ts);
+        ht_solve += ht_us(ts, te);
+        ht_last_exit = te;
+        if (++ht_n == 1000) {
+          fprintf(stderr, "[sfmx] ba step host times (us, mean of 1000): launches %.1f | wait for S|b %.1f | host solve %.1f | between steps %.1f\n", ht_launch / 1000,
+                  ht_wait / 1000, ht_solve / 1000, ht_between / 1000);
+          ht_launch = ht_wait = ht_solve = ht_between = 0;
+          ht_n = 0;
+        }
+      }
       return status ? SFMX_ERR_SINGULAR : SFMX_OK;
     }
     memcpy(dx_out, hout, (size_t)D * 8);
