@@ -1075,13 +1075,13 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   } while (0)
 #define KLT_LAUNCH_MSUM(RR)                                                                                              \
   do {                                                                                                                   \
-    constexpr size_t lds = KltLds<RR, true>::bytes;                                                                      \
+    const size_t lds = KltLds<RR, true>::bytes + lds_pad;                                                                \
     if (stamps_on && RR == 5) k_klt_track<5, true, false, true><<<n, 64, KltLds<5, true>::bytes, c->stream>>>(KLT_ARGS);  \
     else k_klt_track<RR, false, false, true><<<n, 64, lds, c->stream>>>(KLT_ARGS);                                       \
   } while (0)
 #define KLT_LAUNCH_PIPE_MSUM(RR)                                                                                             \
   do {                                                                                                                       \
-    constexpr size_t lds = KltLds<RR, true>::bytes;                                                                          \
+    const size_t lds = KltLds<RR, true>::bytes + lds_pad;                                                                    \
     if (stamps_on && RR == 5) k_klt_track<5, true, true, true><<<n, 64, KltLds<5, true>::bytes, c->stream>>>(KLT_ARGS);       \
     else k_klt_track<RR, false, true, true><<<n, 64, lds, c->stream>>>(KLT_ARGS);                                            \
   } while (0)
@@ -1096,6 +1096,9 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   //   SFMX_KLT_PIPE=0|1        the sums over the first 64 pixels issued under the second half of the sample grid (radius 4 / 5);
   //                            default: with the matrix-core sums at radius 5 when the launch holds one to 2.5 waves per SIMD
   //                            (167 against 174 us at T = 1 564; slower for a lone wave and above ~3 waves per SIMD).
+  // SFMX_KLT_LDS_PAD=bytes (experiment): extra dynamic LDS per workgroup of the matrix-core variants -- how much the other lanes'
+  // kernels depend on the LDS the resident KLT waves leave free on a CU
+  const size_t lds_pad = getenv("SFMX_KLT_LDS_PAD") ? (size_t)atoi(getenv("SFMX_KLT_LDS_PAD")) : 0;
   const char* sums_env = getenv("SFMX_KLT_SUMS");
   const char* pipe_env = getenv("SFMX_KLT_PIPE");
   const bool msum = sums_env ? sums_env[0] == 'm' : r >= 2;
