@@ -1,1 +1,3 @@
-python tools/ab_inproc.py --reps 30 --passes 3 "pad0:" "pad2560:SFMX_KLT_LDS_PAD=2560" "pad9000:SFMX_KLT_LDS_PAD=9000" > gpurun_out/r03_ab_inproc_kltlds.txt 2>&1
+python -m pytest tests -m gpu -x -q > gpurun_out/r03_final2_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03_final2_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03_final2_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/r03_final2_smoke.log
+bash tools/profile_round.sh r03 > gpurun_out/r03_profile_round3.log 2>&1
