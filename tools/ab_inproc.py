@@ -36,7 +36,7 @@ for _ in range(3):
     one()
 ms = {n: [] for n, _ in variants}
 klt = {n: [] for n, _ in variants}
-extra = {n: {k: [] for k in ("sec_lane_b_busy", "sec_join_wait", "sec_m_kf", "sec_feed_wait", "sec_m_step")} for n, _ in variants}
+extra = {n: {k: [] for k in ("sec_lane_b_busy", "sec_join_wait", "sec_m_kf", "sec_feed_wait", "sec_m_step", "sec_m_ransac", "sec_shi_wait")} for n, _ in variants}
 ref_log = None
 for rep in range(args.reps):
     for name, env in variants:
