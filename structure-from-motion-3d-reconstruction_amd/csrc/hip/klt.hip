@@ -1035,7 +1035,7 @@ extern "C" int sfmx_klt_track(sfmx_ctx* c, const sfmx_pyramid* pa, const sfmx_py
   KernelTimer t(c);
   t.start();
   prof_begin(c, KID_KLT);
-  static const int klt_prio = getenv("SFMX_KLT_WAVE_PRIO") ? atoi(getenv("SFMX_KLT_WAVE_PRIO")) : 0;
+  const int klt_prio = getenv("SFMX_KLT_WAVE_PRIO") ? atoi(getenv("SFMX_KLT_WAVE_PRIO")) : 0;  // read per call (A/B inside one process)
   static const bool stamps_on = getenv("SFMX_KLT_STAMPS") != nullptr;  // diagnostic build of the kernel, see k_klt_track
   unsigned long long* d_stamps = nullptr;
   if (stamps_on) {

@@ -1,1 +1,1 @@
-python tools/ab_inproc.py --reps 30 --passes 3 "pf2:" "pf3:SFMX_PREFETCH_WORKERS=3" "pf4:SFMX_PREFETCH_WORKERS=4" "pf3+depth6:SFMX_PREFETCH_WORKERS=3,SFMX_PREFETCH_DEPTH=8" > gpurun_out/r03_ab_inproc_pf.txt 2>&1
+python tools/ab_inproc.py --reps 30 --passes 3 "sweeps:" "tile:SFMX_SHI_MODE=tile" > gpurun_out/r03_ab_inproc_shi.txt 2>&1
