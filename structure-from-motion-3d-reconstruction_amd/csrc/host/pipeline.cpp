@@ -1387,7 +1387,8 @@ void run_pipeline(sfmx_ctx* ctx, FrameSource& src, const std::vector<FrameMeta>&
       std::vector<PooledCtx*> made;
       for (const char* c = order; *c; ++c) {
         const int role = *c == 'P' ? ContextPool::PREFETCH : *c == 'T' ? ContextPool::TRACKER : *c == 'B' ? ContextPool::LANE_B
-                         : *c == 'C' ? ContextPool::LANE_C : *c == 'A' ? ContextPool::LANE_A : *c == 'E' ? ContextPool::LANE_E : 0;
+                         : *c == 'C' ? ContextPool::LANE_C : *c == 'A' ? ContextPool::LANE_A : *c == 'E' ? ContextPool::LANE_E
+                         : *c == 'a' ? ContextPool::LANE_A2 : 0;  // (two 'P' = both prefetch workers' contexts)
         if (role) made.push_back(ContextPool::instance().acquire(dev, 0, role));
       }
       for (PooledCtx* pc : made) ContextPool::instance().release(pc);
