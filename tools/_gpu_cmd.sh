@@ -1,1 +1,2 @@
-for i in 1 2 3; do for O in TBPCAE TBPCAEa TBPCAaE TBPaCAE TBPPCAEa TBaPCAE; do echo "ORDER=$O $(SFMX_LANE_ORDER=$O python bench.py --steps 24 --warmup 4 --no-cpu-baseline --batched-probe 0 --sharded-probe 0 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["value"], d["ms_per_step"], d["passes_bit_identical"])')"; done; done > gpurun_out/r03_ab_order.txt 2>&1
+python -m pytest tests -m gpu -x -q > gpurun_out/r03_final3_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03_final3_tests.log
+python tools/microbench.py 2>&1 | grep "ba step\|ba build (points" > gpurun_out/r03_final3_microbench_ba.txt
