@@ -888,9 +888,26 @@ int sfmx_shi_tomasi_candidates(sfmx_ctx* c, const sfmx_pyramid* p, double qualit
 // speculative download into pinned memory -- is ~30 launches of 2-30 us kernels: launch-bound when issued
 // one by one (~10 us of host time each).  It is captured ONCE per (buffers, image, parameters) signature
 // into a hipGraph and replayed afterwards: one graph launch + one synchronisation per call.
+// schedule of the corner fixpoint for an image: number of tile passes (0 = the sweep schedule) and the tile kernel's inner rounds.
+// SFMX_SHI_MODE=tile[,passes[,rounds]] | sweeps overrides the choice by image size; read per call (tests / A/B inside one process)
+static int shi_tile_passes(int w, int h, int* rounds_out) {
+  int mode_passes = -1, tile_rounds = 64;  // -1: by image size
+  if (const char* e = getenv("SFMX_SHI_MODE")) {
+    int a = 3, b = 64;
+    if (strncmp(e, "tile", 4) == 0) {
+      mode_passes = 3;
+      if (sscanf(e, "tile,%d,%d", &a, &b) >= 1) { mode_passes = a < 1 ? 1 : (a > 16 ? 16 : a); tile_rounds = b < 1 ? 1 : b; }
+    } else if (strncmp(e, "sweeps", 6) == 0) {
+      mode_passes = 0;
+    }
+  }
+  if (rounds_out) *rounds_out = tile_rounds;
+  (void)w; (void)h;
+  return mode_passes >= 0 ? mode_passes : 3;  // the tile-resident kernel, three passes, at every image size (see below)
+}
 struct ShiGraphKey {
   const void* img; void* d0; void* d1; void* d2; void* d3; void* d4; void* d5; void* d6; void* pin; void* w0; void* w1; void* w2; void* w3;
-  int w, h, md, cap;
+  int w, h, md, cap, tile_passes, tile_rounds;
   double quality;
   bool operator==(const ShiGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
 };
@@ -938,25 +955,13 @@ static int shi_enqueue(sfmx_ctx* c, const sfmx_pyramid* p, double quality, int m
   if (rc) return rc;
   dim3 g((p->w + 63) / 64, (p->h + 3) / 4);
   prof_begin(c, KID_SHI_FIXPOINT);  // init + dense sweeps + work-list sweeps + tail + compaction
-  // Schedule of the fixpoint: the tile-resident kernel (k_shi_tile) for images of a megapixel or more -- there the corner
-  // detection bounds the tracker lane and the tile schedule needs less than half the device time -- and the sweep schedule below
-  // for smaller ones, where the tile kernel's large resident workgroups cost the neighbouring lanes more than they save
-  // (DESIGN.md 4.2).  SFMX_SHI_MODE=tile[,passes[,rounds]] | sweeps overrides; any schedule is exact.
-  static int mode_passes = -1, tile_rounds = 64;  // -1: by image size
-  static const bool tile_parsed = [] {
-    if (const char* e = getenv("SFMX_SHI_MODE")) {
-      int a = 3, b = 64;
-      if (strncmp(e, "tile", 4) == 0) {
-        mode_passes = 3;
-        if (sscanf(e, "tile,%d,%d", &a, &b) >= 1) { mode_passes = a < 1 ? 1 : (a > 16 ? 16 : a); tile_rounds = b < 1 ? 1 : b; }
-      } else if (strncmp(e, "sweeps", 6) == 0) {
-        mode_passes = 0;
-      }
-    }
-    return true;
-  }();
-  (void)tile_parsed;
-  const int tile_passes = mode_passes >= 0 ? mode_passes : ((size_t)p->w * p->h >= (size_t)1000000 ? 3 : 0);
+  // Schedule of the fixpoint: the tile-resident kernel (k_shi_tile), three passes -- 142 us and 3 launches per 640x480 image against
+  // 170 us and ~20 launches for the sweep schedule below, 213 against 460 us at 1920x1080 (profiles/r03_shi_tile_probe.txt).  At VGA
+  // the interleaved A/B of the end of round 3 reads 27.6 against 28.0 ms per 47-frame pass (profiles/r03_ab_inproc_shi2.txt; an
+  // earlier comparison between separate runs had it 4 % slower, when other lanes bounded the pass).  SFMX_SHI_MODE=tile[,passes[,
+  // rounds]] | sweeps overrides; any schedule is exact (the host resolver finishes whatever the device leaves undecided).
+  int tile_rounds = 64;
+  const int tile_passes = shi_tile_passes(p->w, p->h, &tile_rounds);
   if (tile_passes > 0) {
     const size_t lds = shi_tile_lds(min_dist, c->wl_ntaps);
     for (int pass = 0; pass < tile_passes; ++pass) {
@@ -1068,6 +1073,7 @@ int sfmx_shi_tomasi_candidates_pruned(sfmx_ctx* c, const sfmx_pyramid* p, double
   memset(&key, 0, sizeof key);
   key.img = p->base; key.d0 = c->d[0].p; key.d1 = c->d[1].p; key.d2 = c->d[2].p; key.d3 = c->d[3].p; key.d4 = c->d[4].p;
   key.d5 = c->d[5].p; key.d6 = c->d[6].p; key.pin = c->h[2].p; key.w0 = c->wl[0].p; key.w1 = c->wl[1].p; key.w2 = c->wl[2].p; key.w3 = c->wl[3].p; key.w = p->w; key.h = p->h; key.md = min_dist; key.cap = cap;
+  key.tile_passes = shi_tile_passes(p->w, p->h, &key.tile_rounds);
   key.quality = quality;
   bool launched = false;
   if (!no_graph && !c->timing) {

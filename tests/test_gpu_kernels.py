@@ -187,6 +187,30 @@ def test_corner_pick_for_every_min_distance_vs_oracle(ctx, min_distance):
     To.close()
 
 
+@pytest.mark.parametrize("mode", ["tile", "tile,2", "tile,5", "sweeps"])
+@pytest.mark.parametrize("min_distance", [2, 8, 16])
+def test_corner_schedules_give_the_oracles_pick(ctx, mode, min_distance, monkeypatch):
+    """Every schedule of the corner fixpoint (tile-resident kernel with 2 / 3 / 5 passes, sweep schedule) leaves a different set of
+    undecided candidates to the host resolver and must end in the same pick: tracks after a reset and a replenish, bit-equal to
+    the oracle's (T:286-300), at 640x480 where the tile schedule is not the default."""
+    monkeypatch.setenv("SFMX_SHI_MODE", mode)
+    pipe = importlib.import_module(H.PKG_NAME + ".pipeline")
+    seq = synth.make_sequence(2, 640, 480, 0.4, n_blobs=15000, seed=70 + min_distance)
+    kw = dict(max_tracks=3000, min_tracks=2900, quality=0.01, min_distance=min_distance, levels=3, radius=5, iters=10, fb=1.0)
+    Tg = pipe.Tracker(ctx, 640, 480, **kw)
+    To = H.Tracker(O, "orc", **kw)
+    for f in range(2):
+        Tg.step(seq["images"][f])
+        To.step(seq["images"][f])
+        gxy, gid = Tg.tracks()
+        oxy, oid = To.tracks()
+        assert np.array_equal(gid, oid), (mode, min_distance, f)
+        H.assert_bits_equal(gxy, oxy, f"tracks mode={mode} min_distance={min_distance} frame {f}")
+    assert len(gid) > 0
+    Tg.close()
+    To.close()
+
+
 def test_fp64_matrix_core_adds_in_order():
     """What the KLT kernel's ordered sums rest on (csrc/hip/klt.hip, MSUM): v_mfma_f64_4x4x4 applies its four k-terms as fused
     multiply-adds in ascending k, each rounded to FP64 -- with B = 1.0 four of the reference's additions in order -- keeps

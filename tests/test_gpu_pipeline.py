@@ -292,7 +292,7 @@ def test_async_lanes_do_not_change_results(tmp_path):
                   {"SFMX_NO_EDGE_LANE": "1"}, {"SFMX_NO_RANSAC_LANE": "1", "SFMX_PREFETCH_WORKERS": "1"},
                   {"SFMX_BA_NO_FUSE": "1", "SFMX_BA_NO_WAVE_PRIO": "1"}, {"SFMX_BA_EXPAND": "split", "SFMX_BA_NO_POLL": "1"},
                   {"SFMX_BA_SOLVE": "device"}, {"SFMX_BA_RESIDENT": "1"}, {"SFMX_SPIN_US": "200"}, {"SFMX_NO_PRELOAD": "1"}, {"SFMX_RANSAC_LANES": "2"}, {"SFMX_KLT_K": "0"}, {"SFMX_KLT_K": "2"}, {"SFMX_KLT_K": "4"}, {"SFMX_RANSAC_HYP": "legacy"}, {"SFMX_JOIN_C_EARLY": "1"}, {"SFMX_VERIFY_LATE": "1"}, {"SFMX_VERIFY_LATE": "1", "SFMX_JOIN_C_EARLY": "1", "SFMX_RANSAC_LANES": "1"}, {"SFMX_BA_POINTS": "global", "SFMX_BA_PUBLISH": "last", "SFMX_BA_TILE": "64"}, {"SFMX_BA_TILE": "16", "SFMX_BA_PTS": "1"}, {"SFMX_BA_PTS": "4"}, {"SFMX_KLT_PIPE": "1"}, {"SFMX_KLT_PIPE": "0"}, {"SFMX_KLT_SUMS": "valu"}, {"SFMX_KLT_SUMS": "valu", "SFMX_KLT_PIPE": "1"},
-                  {"SFMX_SHI_SWEEPS": "5,8,40", "SFMX_SHI_INNER": "3"}, {"SFMX_SHI_SWEEPS": "2,1,0"}):
+                  {"SFMX_SHI_MODE": "tile"}, {"SFMX_SHI_MODE": "tile,2"}, {"SFMX_SHI_MODE": "sweeps"}, {"SFMX_SHI_SWEEPS": "5,8,40", "SFMX_SHI_INNER": "3"}, {"SFMX_SHI_SWEEPS": "2,1,0"}):
         out = os.path.join(root, f"out{len(outs)}")
         p = subprocess.run([pipe.CLI_PATH, root, out, "--config", os.path.join(root, "cfg.json")], capture_output=True, text=True,
                            cwd=root, env={**os.environ, **extra})
