@@ -16,7 +16,7 @@ args = ap.parse_args()
 variants = []
 for v in args.variants:
     name, _, kv = v.partition(":")
-    variants.append((name, dict(x.split("=", 1) for x in kv.split(",") if x)))
+    variants.append((name, dict(x.split("=", 1) for x in kv.split(";" if ";" in kv else ",") if x)))  # K=V pairs separated by "," (or ";" when a value holds a comma)
 keys = sorted({k for _, e in variants for k in e})
 pipe = importlib.import_module(I.PKG + ".pipeline")
 seq = I.synth.make_sequence(47, 640, 480, 0.3, n_blobs=20000, seed=7)
