@@ -1,1 +1,3 @@
-python tools/ab_inproc.py --reps 30 --passes 3 "tile3:" "tile2:SFMX_SHI_MODE=tile,2;" "tile3+pf3:SFMX_PREFETCH_WORKERS=3" "sweeps:SFMX_SHI_MODE=sweeps" > gpurun_out/r03_ab_inproc_shi3.txt 2>&1
+python -m pytest tests -m gpu -x -q > gpurun_out/r03_final4_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r03_final4_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03_final4_smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/r03_final4_smoke.log
+bash tools/profile_round.sh r03 > gpurun_out/r03_profile_round4.log 2>&1
