@@ -1,1 +1,1 @@
-for i in 1 2 3; do for T in 8 4 6 12; do echo "HOST_THREADS=$T $(SFMX_HOST_THREADS=$T python bench.py --steps 24 --warmup 4 --no-cpu-baseline --batched-probe 0 --sharded-probe 0 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.readline()); print(d["value"], d["ms_per_step"], d["passes_bit_identical"])')"; done; done > gpurun_out/r03_ab_host_threads.txt 2>&1
+python tools/ab_inproc.py --reps 30 --passes 3 "replay1:" "replay2:SFMX_REPLAY_THREADS=2" "replay4:SFMX_REPLAY_THREADS=4" > gpurun_out/r03_ab_inproc_replay.txt 2>&1
